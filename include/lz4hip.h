@@ -1,0 +1,173 @@
+/*
+ * lz4hip.h -- C ABI of liblz4hip.so: the MI355X (gfx950) LZ4 block codec that
+ * sits behind pierrec/lz4 v4's Go API for its hot path (block codec, xxh32
+ * block checksums, frame block step, frame assembly).
+ *
+ * Plain C: pointers and sizes only.  "d_" pointers are DEVICE pointers
+ * (hipMalloc'ed memory of the current device), "h_"/unprefixed pointers in the
+ * host-pointer entry points are ordinary host memory.  `stream` is a
+ * hipStream_t passed as void* (NULL = the default stream).  Device entry points
+ * are asynchronous on `stream`, allocate nothing and keep no pointer after
+ * return; host-pointer entry points are synchronous.
+ *
+ * Every entry point cites the reference interface it replaces (paths relative
+ * to the pierrec/lz4 checkout).  The Go-side binding is shown in INTEGRATION.md.
+ *
+ * Return convention of the block compressors (per block, in d_result[b]):
+ *   n > 0   compressed size                         -> (n, nil)
+ *   0       incompressible (only if dst_len<bound)  -> (0, nil)
+ *  -1       dst too small                           -> (0, ErrInvalidSourceShortBuffer)
+ * Block decoder (d_out_len[b]): n >= 0 bytes written, or -1 for every failure
+ * (corrupt input, short dst, short dict) -> (0, ErrInvalidSourceShortBuffer),
+ * as internal/lz4block/block.go:48-51 folds the decoder's -1/-2/-3.
+ */
+#ifndef LZ4HIP_H
+#define LZ4HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Function status codes (distinct from the per-block result convention). */
+#define LZ4HIP_OK 0
+#define LZ4HIP_ERR_ARG (-1)     /* bad argument (size, alignment, NULL) */
+#define LZ4HIP_ERR_HIP (-2)     /* a HIP runtime call failed: lz4hip_last_error() */
+#define LZ4HIP_ERR_SHORT (-3)   /* host-pointer frame calls: dst_cap too small */
+#define LZ4HIP_ERR_FRAME (-4)   /* lz4errors.ErrInvalidFrame */
+#define LZ4HIP_ERR_HEADER_CHECKSUM (-5) /* ErrInvalidHeaderChecksum */
+#define LZ4HIP_ERR_BLOCK_SIZE (-6)      /* ErrOptionInvalidBlockSize */
+#define LZ4HIP_ERR_BLOCK_CHECKSUM (-7)  /* ErrInvalidBlockChecksum */
+#define LZ4HIP_ERR_FRAME_CHECKSUM (-8)  /* ErrInvalidFrameChecksum */
+#define LZ4HIP_ERR_BLOCK (-9)           /* ErrInvalidSourceShortBuffer inside a frame */
+
+/* Block sizes: internal/lz4block/blocks.go:6-12 (lz4.go:16-24 asserts equality). */
+#define LZ4HIP_BLOCK_64KB (1u << 16)
+#define LZ4HIP_BLOCK_256KB (1u << 18)
+#define LZ4HIP_BLOCK_1MB (1u << 20)
+#define LZ4HIP_BLOCK_4MB (1u << 22)
+
+/* dst_mode of the batched compressors. */
+#define LZ4HIP_DST_FRAME 0 /* dst_len = len(src): lz4stream/block.go:229 */
+#define LZ4HIP_DST_BOUND 1 /* dst_len = CompressBlockBound(len(src)) */
+
+/* Frame flags (options.go: BlockChecksumOption, ChecksumOption, SizeOption) and
+ * the entry-point quirk of writer.go:220-233 (io.Copy -> Writer.ReadFrom writes
+ * a trailing zero-length raw block when len(src) is a block multiple). */
+#define LZ4HIP_F_BLOCK_CHECKSUM 1u
+#define LZ4HIP_F_CONTENT_CHECKSUM 2u
+#define LZ4HIP_F_CONTENT_SIZE 4u
+#define LZ4HIP_F_READFROM 8u
+
+const char *lz4hip_last_error(void);          /* thread-local text of the last failure */
+int lz4hip_device_count(void);                /* GPUs visible; 0 if none */
+const char *lz4hip_version(void);
+
+/* lz4.CompressBlockBound: lz4.go:27-29, internal/lz4block/block.go:40-42. Host only. */
+size_t lz4hip_compress_bound(size_t n);
+
+/* ------------------------------------------------------------------------
+ * Batched device entry points (the hot path).
+ * d_src holds n bytes cut into ceil(n/block_size) blocks (the last may be
+ * short); it must be 16-byte aligned and block_size one of the four sizes
+ * above.  Block b compresses into d_dst + b*dst_stride (dst_stride >= the
+ * dst_len implied by dst_mode, multiple of 16).
+ * ---------------------------------------------------------------------- */
+
+/* Fast level: (*Compressor).CompressBlock, internal/lz4block/block.go:105-295,
+ * as called per block by FrameDataBlock.Compress, lz4stream/block.go:232-234. */
+int lz4hip_compress_fast_blocks(const void *d_src, size_t n, uint32_t block_size, int dst_mode,
+                                void *d_dst, size_t dst_stride, int32_t *d_result, void *stream);
+
+/* HC level: (*CompressorHC).CompressBlock, internal/lz4block/block.go:319-481,
+ * lz4stream/block.go:235-237.  depth = chain depth (0 => 65536); the frame path
+ * passes the CompressionLevel constant (options.go:154-165).
+ * d_workspace: lz4hip_hc_workspace_bytes(n_blocks) bytes, 256-byte aligned. */
+size_t lz4hip_hc_workspace_bytes(size_t n_blocks);
+int lz4hip_compress_hc_blocks(const void *d_src, size_t n, uint32_t block_size, uint32_t depth,
+                              int dst_mode, void *d_dst, size_t dst_stride, int32_t *d_result,
+                              void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* UncompressBlock over n_blocks independent blocks: internal/lz4block/block.go:44-52,
+ * decode_amd64.s:24-448 / decode_other.go:10-137, as called by
+ * FrameDataBlock.Uncompress, lz4stream/block.go:319-329.
+ * Block b's input is d_src + d_src_off[b], length d_size_words[b] & 0x7fffffff;
+ * bit 31 set means stored raw (copied).  Output goes to d_dst + b*dst_stride,
+ * at most dst_len bytes.  A zero-length compressed input yields 0 (block.go:45-47). */
+int lz4hip_uncompress_blocks(const void *d_src, const uint64_t *d_src_off,
+                             const uint32_t *d_size_words, size_t n_blocks, void *d_dst,
+                             size_t dst_stride, uint32_t dst_len, int32_t *d_out_len,
+                             void *stream);
+
+/* xxh32.ChecksumZero per block: internal/xxh32/xxh32zero.go:142-184, as used for
+ * block checksums over UNCOMPRESSED bytes, lz4stream/block.go:248-250,330-335.
+ * Span i is d_base + (d_off ? d_off[i] : i*stride), length d_len ? d_len[i] :
+ * min(stride, n - i*stride). */
+int lz4hip_xxh32_blocks(const void *d_base, size_t n, size_t stride, const uint64_t *d_off,
+                        const int32_t *d_len, size_t n_spans, uint32_t *d_out, void *stream);
+
+/* Streaming content checksum (XXHZero.Write over blocks in order + Sum32):
+ * internal/xxh32/xxh32zero.go:58-139 incl. the uint32 truncation of totalLen
+ * (:113-118); lz4stream/block.go:257-259, frame.go:69-71.  Serial by nature:
+ * one wave walks the n bytes.  Writes one uint32 to d_out. */
+int lz4hip_xxh32_stream(const void *d_src, size_t n, uint32_t *d_out, void *stream);
+
+/* Frame assembly on device: FrameDescriptor.Write (frame.go:144-167),
+ * FrameDataBlock.Write per block (lz4stream/block.go:254-276: size word,
+ * payload or raw src when d_result[b] <= 0, checksum word unless 0) and
+ * Frame.CloseW (frame.go:59-74).
+ *  - lz4hip_frame_layout: exclusive scan of the per-block entry sizes;
+ *    d_entry_off[b] = offset of block b's size word from the frame start,
+ *    d_entry_off[n_blocks] = offset of the end mark, d_frame_len[0] = total.
+ *    first_off = bytes before the first entry (header length, or the span
+ *    start of a GPU shard when frames are assembled across GPUs).
+ *  - lz4hip_frame_scatter: writes the entries at those offsets.
+ *  - lz4hip_frame_header / trailer are tiny host helpers (7/15 and 4/8 bytes).
+ */
+int lz4hip_frame_layout(const int32_t *d_result, size_t n, uint32_t block_size, size_t n_blocks,
+                        const uint32_t *d_block_xxh /* NULL: no block checksums */,
+                        uint64_t first_off, uint64_t *d_entry_off /* n_blocks+1 */,
+                        uint32_t *d_size_words /* n_blocks, may be NULL */, void *stream);
+int lz4hip_frame_scatter(const void *d_src, size_t n, uint32_t block_size, const void *d_comp,
+                         size_t comp_stride, const int32_t *d_result,
+                         const uint32_t *d_block_xxh, const uint64_t *d_entry_off,
+                         size_t n_blocks, void *d_frame, uint64_t frame_base, void *stream);
+size_t lz4hip_frame_header(uint8_t *h_dst16, uint32_t block_size, uint32_t flags,
+                           uint64_t content_size);
+size_t lz4hip_frame_trailer(uint8_t *h_dst8, uint32_t flags, uint32_t content_xxh);
+/* Upper bound of a frame of n source bytes. */
+size_t lz4hip_frame_bound(size_t n, uint32_t block_size, uint32_t flags);
+
+/* ------------------------------------------------------------------------
+ * Host-pointer entry points: what the cgo shim binds.
+ * They stage through device buffers owned by the call and synchronise.
+ * ---------------------------------------------------------------------- */
+
+/* lz4.CompressBlock / Compressor.CompressBlock: lz4.go:70-94. */
+int64_t lz4hip_compress_block(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_len);
+/* lz4.CompressBlockHC / CompressorHC.CompressBlock: lz4.go:121-131. */
+int64_t lz4hip_compress_block_hc(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_len,
+                                 uint32_t depth);
+/* lz4.UncompressBlock / UncompressBlockWithDict: lz4.go:37-49. */
+int64_t lz4hip_uncompress_block(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_len,
+                                const uint8_t *dict, size_t dict_len);
+/* xxh32.ChecksumZero: internal/xxh32/xxh32zero.go:142. */
+uint32_t lz4hip_xxh32(const uint8_t *p, size_t n);
+
+/* Writer.Write(src)+Close(), or io.Copy(zw, src) with LZ4HIP_F_READFROM:
+ * writer.go:74-145,173-184,199-242.  level 0 = Fast, else HC depth.
+ * Returns the frame length or a negative LZ4HIP_ERR_*. */
+int64_t lz4hip_frame_compress(const uint8_t *src, size_t n, uint32_t block_size, uint32_t flags,
+                              uint32_t level, uint64_t content_size, uint8_t *dst,
+                              size_t dst_cap);
+/* io.ReadAll(lz4.NewReader(frame)) for a frame with independent blocks:
+ * reader.go:81-196, lz4stream/block.go:279-340, frame.go:80-131,169-200.
+ * Returns decoded length or a negative LZ4HIP_ERR_*. */
+int64_t lz4hip_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LZ4HIP_H */

@@ -1,0 +1,563 @@
+// abi.hip -- the extern "C" surface of liblz4hip.so (see include/lz4hip.h).
+//
+// Device entry points validate shapes on the host before any launch (a faulting
+// kernel can reset the whole node) and are asynchronous.  Host-pointer entry
+// points own their device buffers for the duration of the call.
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+using namespace lz4hip;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char *what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return LZ4HIP_ERR_HIP;
+}
+#define HIPCHK(call)                                      \
+    do {                                                  \
+        hipError_t e_ = (call);                           \
+        if (e_ != hipSuccess) return hip_fail(e_, #call); \
+    } while (0)
+
+bool valid_block_size(uint32_t bs) {
+    return bs == LZ4HIP_BLOCK_64KB || bs == LZ4HIP_BLOCK_256KB || bs == LZ4HIP_BLOCK_1MB ||
+           bs == LZ4HIP_BLOCK_4MB;
+}
+int block_size_index(uint32_t bs) {  // blocks.go:22-36
+    switch (bs) {
+    case LZ4HIP_BLOCK_64KB: return 4;
+    case LZ4HIP_BLOCK_256KB: return 5;
+    case LZ4HIP_BLOCK_1MB: return 6;
+    case LZ4HIP_BLOCK_4MB: return 7;
+    }
+    return 0;
+}
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+constexpr size_t kHcSlots = 2048;               // resident workgroups of the HC kernel
+constexpr size_t kHcSlotBytes = 2 * 65536 * 4;  // hashTable + chainTable
+constexpr size_t kMaxSingleBlock = 1u << 30;    // int32 positions inside a block
+
+// Host xxh32 for the 2/10-byte frame descriptor only (frame.go:202-204).
+uint32_t rol(uint32_t u, int k) { return (u << k) | (u >> (32 - k)); }
+uint32_t host_xxh32_short(const uint8_t *p, size_t n) {  // n < 16
+    uint32_t h = (uint32_t)n + 374761393u;
+    size_t i = 0;
+    for (; i + 4 <= n; i += 4) {
+        uint32_t w;
+        memcpy(&w, p + i, 4);
+        h = rol(h + w * 3266489917u, 17) * 668265263u;
+    }
+    for (; i < n; i++) h = rol(h + p[i] * 374761393u, 11) * 2654435761u;
+    h ^= h >> 15;
+    h *= 2246822519u;
+    h ^= h >> 13;
+    h *= 3266489917u;
+    h ^= h >> 16;
+    return h;
+}
+
+// RAII device buffer for the host-pointer entry points.
+struct DevBuf {
+    void *p = nullptr;
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    template <class T> T *as() { return static_cast<T *>(p); }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char *lz4hip_last_error(void) { return g_err.c_str(); }
+const char *lz4hip_version(void) { return "lz4hip 0.1 (gfx950)"; }
+
+int lz4hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+size_t lz4hip_compress_bound(size_t n) { return n + n / 255 + 16; }
+
+int lz4hip_compress_fast_blocks(const void *d_src, size_t n, uint32_t block_size, int dst_mode,
+                                void *d_dst, size_t dst_stride, int32_t *d_result, void *stream) {
+    if (!valid_block_size(block_size)) return fail(LZ4HIP_ERR_ARG, "invalid block size");
+    if (dst_mode != LZ4HIP_DST_FRAME && dst_mode != LZ4HIP_DST_BOUND)
+        return fail(LZ4HIP_ERR_ARG, "invalid dst_mode");
+    if (n == 0) return LZ4HIP_OK;
+    if (!d_src || !d_dst || !d_result) return fail(LZ4HIP_ERR_ARG, "null pointer");
+    if (!aligned16(d_src) || !aligned16(d_dst) || (dst_stride & 15))
+        return fail(LZ4HIP_ERR_ARG, "d_src, d_dst and dst_stride must be 16-byte aligned");
+    const size_t need =
+        dst_mode == LZ4HIP_DST_FRAME ? block_size : lz4hip_compress_bound(block_size);
+    if (dst_stride < need) return fail(LZ4HIP_ERR_ARG, "dst_stride smaller than dst_len");
+    const size_t nb = (n + block_size - 1) / block_size;
+    HIPCHK(launch_fast((const uint8_t *)d_src, n, block_size, nb, dst_mode, 0, (uint8_t *)d_dst,
+                       dst_stride, d_result, (hipStream_t)stream));
+    return LZ4HIP_OK;
+}
+
+size_t lz4hip_hc_workspace_bytes(size_t n_blocks) {
+    return (n_blocks < kHcSlots ? (n_blocks ? n_blocks : 1) : kHcSlots) * kHcSlotBytes;
+}
+
+int lz4hip_compress_hc_blocks(const void *d_src, size_t n, uint32_t block_size, uint32_t depth,
+                              int dst_mode, void *d_dst, size_t dst_stride, int32_t *d_result,
+                              void *d_workspace, size_t workspace_bytes, void *stream) {
+    if (!valid_block_size(block_size)) return fail(LZ4HIP_ERR_ARG, "invalid block size");
+    if (dst_mode != LZ4HIP_DST_FRAME && dst_mode != LZ4HIP_DST_BOUND)
+        return fail(LZ4HIP_ERR_ARG, "invalid dst_mode");
+    if (n == 0) return LZ4HIP_OK;
+    if (!d_src || !d_dst || !d_result || !d_workspace) return fail(LZ4HIP_ERR_ARG, "null pointer");
+    if (!aligned16(d_src) || !aligned16(d_dst) || (dst_stride & 15) || !aligned16(d_workspace))
+        return fail(LZ4HIP_ERR_ARG, "pointers and dst_stride must be 16-byte aligned");
+    const size_t need =
+        dst_mode == LZ4HIP_DST_FRAME ? block_size : lz4hip_compress_bound(block_size);
+    if (dst_stride < need) return fail(LZ4HIP_ERR_ARG, "dst_stride smaller than dst_len");
+    const size_t nb = (n + block_size - 1) / block_size;
+    size_t slots = workspace_bytes / kHcSlotBytes;
+    if (slots > kHcSlots) slots = kHcSlots;
+    if (slots == 0 || (slots < nb && slots < 64))
+        return fail(LZ4HIP_ERR_ARG, "workspace smaller than lz4hip_hc_workspace_bytes(n_blocks)");
+    HIPCHK(launch_hc((const uint8_t *)d_src, n, block_size, nb, depth, dst_mode, 0,
+                     (uint8_t *)d_dst, dst_stride, d_result, (uint32_t *)d_workspace, slots,
+                     (hipStream_t)stream));
+    return LZ4HIP_OK;
+}
+
+int lz4hip_uncompress_blocks(const void *d_src, const uint64_t *d_src_off,
+                             const uint32_t *d_size_words, size_t n_blocks, void *d_dst,
+                             size_t dst_stride, uint32_t dst_len, int32_t *d_out_len,
+                             void *stream) {
+    if (n_blocks == 0) return LZ4HIP_OK;
+    if (!d_src || !d_src_off || !d_size_words || !d_dst || !d_out_len)
+        return fail(LZ4HIP_ERR_ARG, "null pointer");
+    if (dst_stride < dst_len) return fail(LZ4HIP_ERR_ARG, "dst_stride smaller than dst_len");
+    if (dst_len > kMaxSingleBlock) return fail(LZ4HIP_ERR_ARG, "dst_len too large");
+    if (n_blocks > 0x7fffffffu) return fail(LZ4HIP_ERR_ARG, "too many blocks");
+    HIPCHK(launch_decode((const uint8_t *)d_src, d_src_off, d_size_words, n_blocks,
+                         (uint8_t *)d_dst, dst_stride, dst_len, 0, d_out_len,
+                         (hipStream_t)stream));
+    return LZ4HIP_OK;
+}
+
+int lz4hip_xxh32_blocks(const void *d_base, size_t n, size_t stride, const uint64_t *d_off,
+                        const int32_t *d_len, size_t n_spans, uint32_t *d_out, void *stream) {
+    if (n_spans == 0) return LZ4HIP_OK;
+    if (!d_base || !d_out) return fail(LZ4HIP_ERR_ARG, "null pointer");
+    if (!d_off && stride == 0) return fail(LZ4HIP_ERR_ARG, "stride is 0 and no offsets given");
+    HIPCHK(launch_xxh32_blocks((const uint8_t *)d_base, n, stride, d_off, d_len, n_spans, d_out,
+                               (hipStream_t)stream));
+    return LZ4HIP_OK;
+}
+
+int lz4hip_xxh32_stream(const void *d_src, size_t n, uint32_t *d_out, void *stream) {
+    if (!d_out || (!d_src && n)) return fail(LZ4HIP_ERR_ARG, "null pointer");
+    HIPCHK(launch_xxh32_stream((const uint8_t *)d_src, n, d_out, (hipStream_t)stream));
+    return LZ4HIP_OK;
+}
+
+int lz4hip_frame_layout(const int32_t *d_result, size_t n, uint32_t block_size, size_t n_blocks,
+                        const uint32_t *d_block_xxh, uint64_t first_off, uint64_t *d_entry_off,
+                        uint32_t *d_size_words, void *stream) {
+    if (!valid_block_size(block_size)) return fail(LZ4HIP_ERR_ARG, "invalid block size");
+    if (!d_entry_off || (!d_result && n_blocks)) return fail(LZ4HIP_ERR_ARG, "null pointer");
+    HIPCHK(launch_frame_layout(d_result, n, block_size, n_blocks, d_block_xxh, first_off,
+                               d_entry_off, d_size_words, (hipStream_t)stream));
+    return LZ4HIP_OK;
+}
+
+int lz4hip_frame_scatter(const void *d_src, size_t n, uint32_t block_size, const void *d_comp,
+                         size_t comp_stride, const int32_t *d_result,
+                         const uint32_t *d_block_xxh, const uint64_t *d_entry_off,
+                         size_t n_blocks, void *d_frame, uint64_t frame_base, void *stream) {
+    if (!valid_block_size(block_size)) return fail(LZ4HIP_ERR_ARG, "invalid block size");
+    if (n_blocks == 0) return LZ4HIP_OK;
+    if (!d_result || !d_entry_off || !d_frame || (n && (!d_src || !d_comp)))
+        return fail(LZ4HIP_ERR_ARG, "null pointer");
+    HIPCHK(launch_frame_scatter((const uint8_t *)d_src, n, block_size, (const uint8_t *)d_comp,
+                                comp_stride, d_result, d_block_xxh, d_entry_off, n_blocks,
+                                (uint8_t *)d_frame, frame_base, (hipStream_t)stream));
+    return LZ4HIP_OK;
+}
+
+// frame.go:144-167,202-204; frame_gen.go:7-29
+size_t lz4hip_frame_header(uint8_t *dst, uint32_t block_size, uint32_t flags,
+                           uint64_t content_size) {
+    uint16_t f = (1u << 6) | (1u << 5);  // version 1, independent blocks: frame.go:139-142
+    if (flags & LZ4HIP_F_BLOCK_CHECKSUM) f |= 1u << 4;
+    if (flags & LZ4HIP_F_CONTENT_SIZE) f |= 1u << 3;
+    if (flags & LZ4HIP_F_CONTENT_CHECKSUM) f |= 1u << 2;
+    f |= (uint16_t)(block_size_index(block_size) & 7) << 12;
+    const uint32_t magic = 0x184D2204u;
+    memcpy(dst, &magic, 4);
+    size_t k = 4;
+    dst[k++] = (uint8_t)f;
+    dst[k++] = (uint8_t)(f >> 8);
+    if (flags & LZ4HIP_F_CONTENT_SIZE) {
+        memcpy(dst + k, &content_size, 8);
+        k += 8;
+    }
+    dst[k] = (uint8_t)(host_xxh32_short(dst + 4, k - 4) >> 8);
+    return k + 1;
+}
+
+// frame.go:59-74
+size_t lz4hip_frame_trailer(uint8_t *dst, uint32_t flags, uint32_t content_xxh) {
+    memset(dst, 0, 4);
+    if (!(flags & LZ4HIP_F_CONTENT_CHECKSUM)) return 4;
+    memcpy(dst + 4, &content_xxh, 4);
+    return 8;
+}
+
+size_t lz4hip_frame_bound(size_t n, uint32_t block_size, uint32_t flags) {
+    (void)flags;
+    const size_t nb = n / (block_size ? block_size : 1) + 2;
+    return 15 + n + nb * 8 + 8;
+}
+
+/* ---------------- host-pointer entry points ---------------- */
+
+static int64_t compress_one(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_len,
+                            bool hc, uint32_t depth) {
+    if (n > kMaxSingleBlock || dst_len > 0x7fffffffu)
+        return fail(LZ4HIP_ERR_ARG, "block larger than 1 GiB");
+    if ((n && !src) || (dst_len && !dst)) return fail(LZ4HIP_ERR_ARG, "null pointer");
+    DevBuf d_src, d_dst, d_res, d_ws;
+    HIPCHK(d_src.alloc(n + 16));
+    HIPCHK(d_dst.alloc(dst_len + 16));
+    HIPCHK(d_res.alloc(sizeof(int32_t)));
+    if (n) HIPCHK(hipMemcpy(d_src.p, src, n, hipMemcpyHostToDevice));
+    // one block that spans the whole input: cut size = max(n, 1)
+    const uint32_t bs = (uint32_t)(n ? n : 1);
+    if (hc) {
+        HIPCHK(d_ws.alloc(kHcSlotBytes));
+        HIPCHK(launch_hc(d_src.as<uint8_t>(), n, bs, 1, depth, kDstExplicit, (uint32_t)dst_len,
+                         d_dst.as<uint8_t>(), 0, d_res.as<int32_t>(), d_ws.as<uint32_t>(), 1,
+                         nullptr));
+    } else {
+        HIPCHK(launch_fast(d_src.as<uint8_t>(), n, bs, 1, kDstExplicit, (uint32_t)dst_len,
+                           d_dst.as<uint8_t>(), 0, d_res.as<int32_t>(), nullptr));
+    }
+    int32_t r = 0;
+    HIPCHK(hipMemcpy(&r, d_res.p, sizeof r, hipMemcpyDeviceToHost));
+    if (r > 0) HIPCHK(hipMemcpy(dst, d_dst.p, (size_t)r, hipMemcpyDeviceToHost));
+    return r;  // n, 0 or -1: the Go conventions of lz4.go:59-69
+}
+
+int64_t lz4hip_compress_block(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_len) {
+    int64_t r = compress_one(src, n, dst, dst_len, false, 0);
+    return r < -1 ? -1 : r;
+}
+
+int64_t lz4hip_compress_block_hc(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_len,
+                                 uint32_t depth) {
+    int64_t r = compress_one(src, n, dst, dst_len, true, depth);
+    return r < -1 ? -1 : r;
+}
+
+static int64_t uncompress_one(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_len,
+                              const uint8_t *dict, size_t dict_len) {
+    if (n == 0) return 0;  // block.go:45-47
+    if (n > 0x7fffffffu || dst_len > kMaxSingleBlock)
+        return fail(LZ4HIP_ERR_ARG, "block larger than 1 GiB");
+    if (!src || (dst_len && !dst) || (dict_len && !dict))
+        return fail(LZ4HIP_ERR_ARG, "null pointer");
+    // Only the last 64 KiB of a dictionary are reachable (offsets are 16-bit).
+    if (dict_len > 65536) {
+        dict += dict_len - 65536;
+        dict_len = 65536;
+    }
+    DevBuf d_src, d_out, d_meta;
+    HIPCHK(d_src.alloc(n));
+    HIPCHK(d_out.alloc(dict_len + dst_len));  // [dictionary | dst]
+    HIPCHK(d_meta.alloc(32));
+    HIPCHK(hipMemcpy(d_src.p, src, n, hipMemcpyHostToDevice));
+    if (dict_len) HIPCHK(hipMemcpy(d_out.p, dict, dict_len, hipMemcpyHostToDevice));
+    struct {
+        uint64_t off;
+        uint32_t sw;
+        int32_t out;
+    } meta = {0, (uint32_t)n, 0};
+    HIPCHK(hipMemcpy(d_meta.p, &meta, sizeof meta, hipMemcpyHostToDevice));
+    uint8_t *m = d_meta.as<uint8_t>();
+    HIPCHK(launch_decode(d_src.as<uint8_t>(), (const uint64_t *)m, (const uint32_t *)(m + 8), 1,
+                         d_out.as<uint8_t>() + dict_len, 0, (uint32_t)dst_len,
+                         (uint32_t)dict_len, (int32_t *)(m + 12), nullptr));
+    HIPCHK(hipMemcpy(&meta, d_meta.p, sizeof meta, hipMemcpyDeviceToHost));
+    if (meta.out > 0)
+        HIPCHK(hipMemcpy(dst, d_out.as<uint8_t>() + dict_len, (size_t)meta.out,
+                         hipMemcpyDeviceToHost));
+    return meta.out;
+}
+
+int64_t lz4hip_uncompress_block(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_len,
+                                const uint8_t *dict, size_t dict_len) {
+    int64_t r = uncompress_one(src, n, dst, dst_len, dict, dict_len);
+    return r < -1 ? -1 : r;
+}
+
+uint32_t lz4hip_xxh32(const uint8_t *p, size_t n) {
+    DevBuf d_src, d_out;
+    if (d_src.alloc(n + 16) != hipSuccess || d_out.alloc(4) != hipSuccess) {
+        g_err = "hipMalloc failed";
+        return 0;
+    }
+    if (n && hipMemcpy(d_src.p, p, n, hipMemcpyHostToDevice) != hipSuccess) {
+        g_err = "hipMemcpy failed";
+        return 0;
+    }
+    const int32_t len = (int32_t)n;
+    uint32_t out = 0;
+    if (n <= 0x7fffffffu) {
+        DevBuf d_len;
+        if (d_len.alloc(4) != hipSuccess) return 0;
+        (void)hipMemcpy(d_len.p, &len, 4, hipMemcpyHostToDevice);
+        (void)launch_xxh32_blocks(d_src.as<uint8_t>(), n, n ? n : 1, nullptr, d_len.as<int32_t>(),
+                                  1, d_out.as<uint32_t>(), nullptr);
+        (void)hipMemcpy(&out, d_out.p, 4, hipMemcpyDeviceToHost);
+    } else {
+        (void)launch_xxh32_stream(d_src.as<uint8_t>(), n, d_out.as<uint32_t>(), nullptr);
+        (void)hipMemcpy(&out, d_out.p, 4, hipMemcpyDeviceToHost);
+    }
+    return out;
+}
+
+int64_t lz4hip_frame_compress(const uint8_t *src, size_t n, uint32_t block_size, uint32_t flags,
+                              uint32_t level, uint64_t content_size, uint8_t *dst,
+                              size_t dst_cap) {
+    if (!valid_block_size(block_size)) return fail(LZ4HIP_ERR_BLOCK_SIZE, "invalid block size");
+    if ((n && !src) || !dst) return fail(LZ4HIP_ERR_ARG, "null pointer");
+    if (dst_cap < lz4hip_frame_bound(n, block_size, flags))
+        return fail(LZ4HIP_ERR_SHORT, "dst_cap < lz4hip_frame_bound()");
+    const bool bsum = flags & LZ4HIP_F_BLOCK_CHECKSUM, csum = flags & LZ4HIP_F_CONTENT_CHECKSUM;
+    const size_t nb_data = (n + block_size - 1) / block_size;
+    // Close() flushes only pending bytes; ReadFrom writes data[:rn] even when rn == 0
+    // (writer.go:161-167 vs :220-233).
+    const size_t nb =
+        nb_data + (((flags & LZ4HIP_F_READFROM) && n % block_size == 0) ? 1 : 0);
+
+    uint8_t hdr[16], trl[8];
+    const size_t hlen = lz4hip_frame_header(hdr, block_size, flags, content_size);
+
+    DevBuf d_src, d_comp, d_res, d_xxh, d_off, d_frame, d_cs;
+    hipStream_t s_main = nullptr, s_sum = nullptr;
+    HIPCHK(d_src.alloc(n + 16));
+    HIPCHK(d_comp.alloc(nb_data * (size_t)block_size));
+    HIPCHK(d_res.alloc((nb + 1) * sizeof(int32_t)));
+    HIPCHK(d_xxh.alloc((nb + 1) * sizeof(uint32_t)));
+    HIPCHK(d_off.alloc((nb + 1) * sizeof(uint64_t)));
+    HIPCHK(d_frame.alloc(dst_cap));
+    HIPCHK(d_cs.alloc(4));
+    HIPCHK(hipStreamCreate(&s_main));
+    HIPCHK(hipStreamCreate(&s_sum));
+    int rc = LZ4HIP_OK;
+    int64_t total = 0;
+    do {
+#define STEP(call)                        \
+    {                                     \
+        hipError_t e_ = (call);           \
+        if (e_ != hipSuccess) {           \
+            rc = hip_fail(e_, #call);     \
+            break;                        \
+        }                                 \
+    }
+        if (n) STEP(hipMemcpy(d_src.p, src, n, hipMemcpyHostToDevice));
+        STEP(hipMemsetAsync(d_res.p, 0, (nb + 1) * sizeof(int32_t), s_main));
+        // content checksum: serial walk, overlapped on its own stream
+        if (csum) STEP(launch_xxh32_stream(d_src.as<uint8_t>(), n, d_cs.as<uint32_t>(), s_sum));
+        if (nb_data) {
+            if (level == 0) {
+                STEP(launch_fast(d_src.as<uint8_t>(), n, block_size, nb_data, LZ4HIP_DST_FRAME, 0,
+                                 d_comp.as<uint8_t>(), block_size, d_res.as<int32_t>(), s_main));
+            } else {
+                DevBuf d_ws;
+                const size_t slots = nb_data < kHcSlots ? nb_data : kHcSlots;
+                STEP(d_ws.alloc(slots * kHcSlotBytes));
+                STEP(launch_hc(d_src.as<uint8_t>(), n, block_size, nb_data, level,
+                               LZ4HIP_DST_FRAME, 0, d_comp.as<uint8_t>(), block_size,
+                               d_res.as<int32_t>(), d_ws.as<uint32_t>(), slots, s_main));
+                STEP(hipStreamSynchronize(s_main));  // d_ws dies with this scope
+            }
+        }
+        if (bsum)
+            STEP(launch_xxh32_blocks(d_src.as<uint8_t>(), n, block_size, nullptr, nullptr, nb,
+                                     d_xxh.as<uint32_t>(), s_main));
+        STEP(launch_frame_layout(d_res.as<int32_t>(), n, block_size, nb,
+                                 bsum ? d_xxh.as<uint32_t>() : nullptr, hlen,
+                                 d_off.as<uint64_t>(), nullptr, s_main));
+        STEP(launch_frame_scatter(d_src.as<uint8_t>(), n, block_size, d_comp.as<uint8_t>(),
+                                  block_size, d_res.as<int32_t>(),
+                                  bsum ? d_xxh.as<uint32_t>() : nullptr, d_off.as<uint64_t>(), nb,
+                                  d_frame.as<uint8_t>(), 0, s_main));
+        uint64_t end_off = 0;
+        STEP(hipMemcpyAsync(&end_off, d_off.as<uint64_t>() + nb, 8, hipMemcpyDeviceToHost, s_main));
+        STEP(hipStreamSynchronize(s_main));
+        STEP(hipStreamSynchronize(s_sum));
+        uint32_t cs = 0;
+        if (csum) STEP(hipMemcpy(&cs, d_cs.p, 4, hipMemcpyDeviceToHost));
+        const size_t tlen = lz4hip_frame_trailer(trl, flags, cs);
+        if (end_off + tlen > dst_cap) {
+            rc = fail(LZ4HIP_ERR_SHORT, "frame larger than dst_cap");
+            break;
+        }
+        memcpy(dst, hdr, hlen);
+        if (end_off > hlen)
+            STEP(hipMemcpy(dst + hlen, d_frame.as<uint8_t>() + hlen, end_off - hlen,
+                           hipMemcpyDeviceToHost));
+        memcpy(dst + end_off, trl, tlen);
+        total = (int64_t)(end_off + tlen);
+#undef STEP
+    } while (0);
+    (void)hipStreamDestroy(s_main);
+    (void)hipStreamDestroy(s_sum);
+    return rc == LZ4HIP_OK ? total : rc;
+}
+
+int64_t lz4hip_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_cap) {
+    if (!src || (dst_cap && !dst)) return fail(LZ4HIP_ERR_ARG, "null pointer");
+    size_t si = 0;
+    auto rd32 = [&](size_t at) {
+        uint32_t v;
+        memcpy(&v, src + at, 4);
+        return v;
+    };
+    // ---- headers: frame.go:80-111,169-200 (host; a few bytes) ----
+    for (;;) {
+        if (n - si < 4) return fail(LZ4HIP_ERR_FRAME, "truncated frame");
+        const uint32_t magic = rd32(si);
+        si += 4;
+        if (magic == 0x184D2204u) break;
+        if (magic >> 8 == 0x184D2A50u >> 8) {  // skippable frame
+            if (n - si < 4) return fail(LZ4HIP_ERR_FRAME, "truncated frame");
+            const uint32_t skip = rd32(si);
+            si += 4;
+            if (n - si < skip) return fail(LZ4HIP_ERR_FRAME, "truncated frame");
+            si += skip;
+            continue;
+        }
+        return fail(LZ4HIP_ERR_FRAME, "invalid frame magic (legacy frames are not handled)");
+    }
+    if (n - si < 3) return fail(LZ4HIP_ERR_FRAME, "truncated frame");
+    const size_t d0 = si;
+    const uint16_t f = (uint16_t)(src[si] | (src[si + 1] << 8));
+    si += 2;
+    if (f >> 3 & 1) {
+        if (n - si < 9) return fail(LZ4HIP_ERR_FRAME, "truncated frame");
+        si += 8;
+    }
+    if ((uint8_t)(host_xxh32_short(src + d0, si - d0) >> 8) != src[si])
+        return fail(LZ4HIP_ERR_HEADER_CHECKSUM, "invalid header checksum");
+    si += 1;
+    const int idx = f >> 12 & 7;
+    if (idx < 4) return fail(LZ4HIP_ERR_BLOCK_SIZE, "invalid block size");
+    const uint32_t bs = 1u << (8 + 2 * idx);
+    const bool bsum = f >> 4 & 1, csum = f >> 2 & 1, independent = f >> 5 & 1;
+    if (!independent)
+        return fail(LZ4HIP_ERR_ARG, "linked-block frames are not handled by the batched decoder");
+
+    // ---- block index: lz4stream/block.go:279-317 (host walk over size words) ----
+    std::vector<uint64_t> off;
+    std::vector<uint32_t> sw, want;
+    for (;;) {
+        if (n - si < 4) return fail(LZ4HIP_ERR_FRAME, "truncated frame");
+        const uint32_t w = rd32(si);
+        si += 4;
+        if (w == 0) break;
+        const uint32_t size = w & 0x7FFFFFFFu;
+        if (size > bs) return fail(LZ4HIP_ERR_BLOCK_SIZE, "block larger than the frame's block size");
+        if (n - si < size) return fail(LZ4HIP_ERR_FRAME, "truncated frame");
+        off.push_back(si);
+        sw.push_back(w);
+        si += size;
+        if (bsum) {
+            if (n - si < 4) return fail(LZ4HIP_ERR_FRAME, "truncated frame");
+            want.push_back(rd32(si));
+            si += 4;
+        }
+    }
+    uint32_t want_cs = 0;
+    if (csum) {
+        if (n - si < 4) return fail(LZ4HIP_ERR_FRAME, "truncated frame");
+        want_cs = rd32(si);
+    }
+    const size_t nb = sw.size();
+    if (nb == 0) {
+        if (csum && want_cs != 0x02CC5D05u)
+            return fail(LZ4HIP_ERR_FRAME_CHECKSUM, "invalid frame checksum");
+        return 0;
+    }
+
+    DevBuf d_src, d_off, d_sw, d_out, d_len, d_xxh, d_cs;
+    HIPCHK(d_src.alloc(n));
+    HIPCHK(d_off.alloc(nb * 8));
+    HIPCHK(d_sw.alloc(nb * 4));
+    HIPCHK(d_out.alloc(nb * (size_t)bs));
+    HIPCHK(d_len.alloc(nb * 4));
+    HIPCHK(d_xxh.alloc(nb * 4));
+    HIPCHK(d_cs.alloc(4));
+    HIPCHK(hipMemcpy(d_src.p, src, n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_off.p, off.data(), nb * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_sw.p, sw.data(), nb * 4, hipMemcpyHostToDevice));
+    HIPCHK(launch_decode(d_src.as<uint8_t>(), d_off.as<uint64_t>(), d_sw.as<uint32_t>(), nb,
+                         d_out.as<uint8_t>(), bs, bs, 0, d_len.as<int32_t>(), nullptr));
+    if (bsum)  // verified on the DECODED bytes: lz4stream/block.go:330-335
+        HIPCHK(launch_xxh32_blocks(d_out.as<uint8_t>(), nb * (size_t)bs, bs, nullptr,
+                                   d_len.as<int32_t>(), nb, d_xxh.as<uint32_t>(), nullptr));
+    std::vector<int32_t> len(nb);
+    std::vector<uint32_t> got(nb);
+    HIPCHK(hipMemcpy(len.data(), d_len.p, nb * 4, hipMemcpyDeviceToHost));
+    if (bsum) HIPCHK(hipMemcpy(got.data(), d_xxh.p, nb * 4, hipMemcpyDeviceToHost));
+    // first failing block wins, in stream order (lz4stream/block.go:187-194)
+    size_t total = 0;
+    bool dense = true;  // every block but the last is full: one contiguous copy
+    for (size_t b = 0; b < nb; b++) {
+        if (len[b] < 0) return fail(LZ4HIP_ERR_BLOCK, "invalid source or destination buffer too short");
+        if (bsum && got[b] != want[b]) return fail(LZ4HIP_ERR_BLOCK_CHECKSUM, "invalid block checksum");
+        if (b + 1 < nb && (uint32_t)len[b] != bs) dense = false;
+        total += (size_t)len[b];
+    }
+    if (total > dst_cap) return fail(LZ4HIP_ERR_SHORT, "dst_cap too small");
+    if (dense) {
+        HIPCHK(hipMemcpy(dst, d_out.p, total, hipMemcpyDeviceToHost));
+    } else {
+        size_t at = 0;
+        for (size_t b = 0; b < nb; b++) {
+            if (len[b])
+                HIPCHK(hipMemcpy(dst + at, d_out.as<uint8_t>() + b * (size_t)bs, (size_t)len[b],
+                                 hipMemcpyDeviceToHost));
+            at += (size_t)len[b];
+        }
+    }
+    if (csum) {  // frame.go:117-131; serial walk over the decoded stream
+        uint32_t cs = 0;
+        if (dense) {
+            HIPCHK(launch_xxh32_stream(d_out.as<uint8_t>(), total, d_cs.as<uint32_t>(), nullptr));
+        } else {
+            DevBuf d_flat;
+            HIPCHK(d_flat.alloc(total));
+            HIPCHK(hipMemcpy(d_flat.p, dst, total, hipMemcpyHostToDevice));
+            HIPCHK(launch_xxh32_stream(d_flat.as<uint8_t>(), total, d_cs.as<uint32_t>(), nullptr));
+            HIPCHK(hipDeviceSynchronize());
+        }
+        HIPCHK(hipMemcpy(&cs, d_cs.p, 4, hipMemcpyDeviceToHost));
+        if (cs != want_cs) return fail(LZ4HIP_ERR_FRAME_CHECKSUM, "invalid frame checksum");
+    }
+    return (int64_t)total;
+}
+
+}  // extern "C"

@@ -1,0 +1,85 @@
+// common.h -- shared device helpers and launch declarations of liblz4hip (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lz4hip.h"
+
+namespace lz4hip {
+
+constexpr int kWave = 64;
+constexpr int kMinMatch = 4;
+constexpr int kWinSize = 1 << 16;
+constexpr int kWinMask = kWinSize - 1;
+constexpr int kMfLimit = 14;  // block.go:25
+constexpr int kAdaptSkipLog = 7;
+constexpr int kDstExplicit = 2;  // internal dst_mode: dst_len given explicitly (single-block API)
+
+__host__ __device__ inline uint32_t compress_bound32(uint32_t n) { return n + n / 255 + 16; }
+
+// Unaligned little-endian loads.  gfx950 global memory runs in unaligned access
+// mode, so these lower to single global_load_dword/dwordx2.
+__device__ __forceinline__ uint32_t ld32(const uint8_t *p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ uint64_t ld64(const uint8_t *p) {
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+
+// block.go:35-38
+__device__ __forceinline__ uint32_t hash6(uint64_t x) {
+    return (uint32_t)(((x << 16) * 227718039650203ULL) >> 48);
+}
+// block.go:298-301
+__device__ __forceinline__ uint32_t hash4(uint32_t x) { return (x * 2654435761u) >> 16; }
+
+// Emits "length - 15" as 255-run + remainder starting at d[di]; returns new di, or
+// -1 when a byte would land at or beyond dlen (block.go:211-219,239-246 and the
+// index panics of :424-428,443-447).  Lane 0 stores; every lane tracks di.
+__device__ __forceinline__ int emit_len_tail(uint8_t *d, int di, int dlen, int v, int lane) {
+    int nff = v / 255;
+    // bytes di .. di+nff-1 are 0xFF, byte di+nff is v % 255
+    if (di + nff >= dlen) return -1;
+    for (int k = lane; k < nff; k += kWave) d[di + k] = 0xFF;
+    if (lane == 0) d[di + nff] = (uint8_t)(v - nff * 255);
+    return di + nff + 1;
+}
+
+// Wave-wide byte copy d[0..n) = s[0..n) (no overlap).
+__device__ __forceinline__ void wave_copy(uint8_t *d, const uint8_t *s, int n, int lane) {
+    for (int k = lane; k < n; k += kWave) d[k] = s[k];
+}
+
+// kernel launchers (defined in the .hip files)
+hipError_t launch_fast(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
+                       uint32_t dst_len_x, uint8_t *dst,
+                       size_t dst_stride, int32_t *result, hipStream_t st);
+hipError_t launch_hc(const uint8_t *src, size_t n, uint32_t bs, size_t nb, uint32_t depth,
+                     int dst_mode,
+                     uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result, uint32_t *ws,
+                     size_t slots, hipStream_t st);
+hipError_t launch_decode(const uint8_t *src, const uint64_t *off, const uint32_t *sw, size_t nb,
+                         uint8_t *dst, size_t dst_stride, uint32_t dst_len, uint32_t prefix,
+                         int32_t *out_len, hipStream_t st);
+hipError_t launch_xxh32_blocks(const uint8_t *base, size_t n, size_t stride, const uint64_t *off,
+                               const int32_t *len, size_t n_spans, uint32_t *out, hipStream_t st);
+hipError_t launch_xxh32_stream(const uint8_t *src, size_t n, uint32_t *out, hipStream_t st);
+hipError_t launch_frame_layout(const int32_t *result, size_t n, uint32_t bs, size_t nb,
+                               const uint32_t *xxh, uint64_t first_off, uint64_t *entry_off,
+                               uint32_t *size_words, hipStream_t st);
+hipError_t launch_frame_scatter(const uint8_t *src, size_t n, uint32_t bs, const uint8_t *comp,
+                                size_t comp_stride, const int32_t *result, const uint32_t *xxh,
+                                const uint64_t *entry_off, size_t nb, uint8_t *frame,
+                                uint64_t frame_base, hipStream_t st);
+
+}  // namespace lz4hip

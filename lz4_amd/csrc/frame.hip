@@ -1,0 +1,121 @@
+// frame.hip -- frame assembly on device.
+//
+// Restates FrameDataBlock.Compress's raw fallback and size word
+// (internal/lz4stream/block.go:238-245), FrameDataBlock.Write (:254-276: u32le
+// size | payload | [u32le checksum unless 0]) for a batch of blocks: an
+// exclusive scan of the entry sizes gives every block its offset in the frame,
+// then one workgroup per block copies its entry there.
+#include "common.h"
+
+namespace lz4hip {
+
+__device__ __forceinline__ uint32_t block_len(size_t n, uint32_t bs, size_t b) {
+    const size_t o = b * (size_t)bs;
+    if (o >= n) return 0;  // trailing empty block of Writer.ReadFrom (writer.go:220-233)
+    const size_t left = n - o;
+    return (uint32_t)(left < bs ? left : bs);
+}
+
+// Single workgroup, 1024 threads: chunked inclusive scan with a running carry.
+__global__ __launch_bounds__(1024) void k_frame_layout(const int32_t *__restrict__ result, size_t n,
+                                                       uint32_t bs, size_t nb,
+                                                       const uint32_t *__restrict__ xxh,
+                                                       uint64_t first_off,
+                                                       uint64_t *__restrict__ entry_off,
+                                                       uint32_t *__restrict__ size_words) {
+    __shared__ uint64_t wave_sum[16];
+    __shared__ uint64_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = first_off;
+    __syncthreads();
+    for (size_t base = 0; base < nb; base += 1024) {
+        const size_t b = base + tid;
+        uint64_t e = 0;
+        if (b < nb) {
+            const int32_t r = result[b];
+            const uint32_t len = block_len(n, bs, b);
+            const uint32_t payload = r > 0 ? (uint32_t)r : len;
+            e = 4 + (uint64_t)payload + ((xxh && xxh[b] != 0) ? 4 : 0);  // :270-272
+            if (size_words) size_words[b] = r > 0 ? payload : (payload | 0x80000000u);
+        }
+        uint64_t v = e;  // inclusive scan inside the wave
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t t = __shfl_up(v, o);
+            if (lane >= o) v += t;
+        }
+        if (lane == 63) wave_sum[wid] = v;
+        __syncthreads();
+        uint64_t pre = carry_s;
+        for (int w = 0; w < wid; w++) pre += wave_sum[w];
+        if (b < nb) entry_off[b] = pre + v - e;
+        __syncthreads();
+        if (tid == 1023) carry_s = pre + v;
+        __syncthreads();
+    }
+    if (tid == 0) entry_off[nb] = carry_s;
+}
+
+__device__ __forceinline__ void put32(uint8_t *p, uint32_t v) {
+    p[0] = (uint8_t)v;
+    p[1] = (uint8_t)(v >> 8);
+    p[2] = (uint8_t)(v >> 16);
+    p[3] = (uint8_t)(v >> 24);
+}
+
+// Workgroup-wide copy with 16-byte stores on the (arbitrarily aligned) destination.
+__device__ __forceinline__ void wg_copy(uint8_t *d, const uint8_t *s, size_t n, int tid, int nt) {
+    size_t head = (16 - (reinterpret_cast<uintptr_t>(d) & 15)) & 15;
+    if (head > n) head = n;
+    for (size_t k = tid; k < head; k += nt) d[k] = s[k];
+    const size_t body = (n - head) / 16;
+    uint4 *d4 = reinterpret_cast<uint4 *>(d + head);
+    const uint8_t *sb = s + head;
+    for (size_t k = tid; k < body; k += nt) {
+        uint4 v;
+        __builtin_memcpy(&v, sb + k * 16, 16);  // unaligned global load
+        d4[k] = v;
+    }
+    const size_t done = head + body * 16;
+    for (size_t k = done + tid; k < n; k += nt) d[k] = s[k];
+}
+
+__global__ __launch_bounds__(256) void k_frame_scatter(
+    const uint8_t *__restrict__ src, size_t n, uint32_t bs, const uint8_t *__restrict__ comp,
+    size_t comp_stride, const int32_t *__restrict__ result, const uint32_t *__restrict__ xxh,
+    const uint64_t *__restrict__ entry_off, size_t nb, uint8_t *__restrict__ frame,
+    uint64_t frame_base) {
+    const size_t b = blockIdx.x;
+    if (b >= nb) return;
+    const int tid = threadIdx.x;
+    const int32_t r = result[b];
+    const uint32_t len = block_len(n, bs, b);
+    const uint32_t payload = r > 0 ? (uint32_t)r : len;
+    uint8_t *e = frame + (entry_off[b] - frame_base);
+    if (tid == 0) put32(e, r > 0 ? payload : (payload | 0x80000000u));
+    const uint8_t *from = r > 0 ? comp + b * comp_stride : src + b * (size_t)bs;
+    wg_copy(e + 4, from, payload, tid, 256);
+    if (xxh && tid == 0) {
+        const uint32_t c = xxh[b];
+        if (c != 0) put32(e + 4 + payload, c);
+    }
+}
+
+hipError_t launch_frame_layout(const int32_t *result, size_t n, uint32_t bs, size_t nb,
+                               const uint32_t *xxh, uint64_t first_off, uint64_t *entry_off,
+                               uint32_t *size_words, hipStream_t st) {
+    hipLaunchKernelGGL(k_frame_layout, dim3(1), dim3(1024), 0, st, result, n, bs, nb, xxh,
+                       first_off, entry_off, size_words);
+    return hipGetLastError();
+}
+
+hipError_t launch_frame_scatter(const uint8_t *src, size_t n, uint32_t bs, const uint8_t *comp,
+                                size_t comp_stride, const int32_t *result, const uint32_t *xxh,
+                                const uint64_t *entry_off, size_t nb, uint8_t *frame,
+                                uint64_t frame_base, hipStream_t st) {
+    if (nb == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_frame_scatter, dim3((unsigned)nb), dim3(256), 0, st, src, n, bs, comp,
+                       comp_stride, result, xxh, entry_off, nb, frame, frame_base);
+    return hipGetLastError();
+}
+
+}  // namespace lz4hip

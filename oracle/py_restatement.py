@@ -130,8 +130,10 @@ def hc_sequences(src, depth):
             si += 1 + ((si - anchor) >> 7)
             continue
         lo = max(si + 1, si + best - WIN)
+        roll = _u32(src, si)  # rolled from si even when lo skips ahead (block.go:399-400)
         for p in range(lo, si + best):
-            hh = hash4(_u32(src, p))
+            roll = (roll >> 8) | (src[p + 3] << 24)
+            hh = hash4(roll)
             chain[p & 0xFFFF] = head[hh]
             head[hh] = p
         yield anchor, si - anchor, best_off, best

@@ -1,0 +1,115 @@
+"""GPU parity of the single-block API (lz4.go:27-131) against the CPU oracle.
+
+Mirrors internal/lz4block/block_test.go and writer_test.go's block cases; every
+call goes through the C ABI (lz4_amd.block -> liblz4hip.so).  Bit-exact bar.
+"""
+import numpy as np
+import pytest
+
+from conftest import load
+
+pytestmark = pytest.mark.gpu
+
+RAW = ["e.txt", "gettysburg.txt", "Mark.Twain-Tom.Sawyer.txt", "pg1661.txt", "pi.txt",
+       "random.data", "repeat.txt", "pg_control.tar", "upperbound.data", "issue51.data",
+       "bzImage_lz4_isolated"]
+
+
+def _gpu_compress(lz, src, dst_len, hc=None):
+    dst = np.zeros(max(dst_len, 1), dtype=np.uint8)[:dst_len]
+    try:
+        n = lz.CompressBlock(src, dst) if hc is None else lz.CompressBlockHC(src, dst, hc)
+    except lz.ErrInvalidSourceShortBuffer:
+        return "ERR"
+    return dst[:n].tobytes()
+
+
+def _cpu_compress(o, src, dst_len, hc=None):
+    try:
+        return (o.CompressBlock(src, dst_len) if hc is None else o.CompressBlockHC(src, hc, dst_len))[1]
+    except o.ErrInvalidSourceShortBuffer:
+        return "ERR"
+
+
+@pytest.mark.parametrize("name", RAW)
+def test_fast_whole_file_byte_identical(name, oracle):
+    """TestCompressUncompressBlock (block_test.go:34-115) + byte identity."""
+    import lz4_amd as lz
+    src = load(name)
+    bound = lz.CompressBlockBound(len(src))
+    assert bound == oracle.CompressBlockBound(len(src))
+    for dst_len in (bound, len(src), len(src) // 2):
+        got = _gpu_compress(lz, src, dst_len)
+        want = _cpu_compress(oracle, src, dst_len)
+        assert got == want, (name, dst_len)
+    z = _gpu_compress(lz, src, bound)
+    out = np.zeros(len(src), dtype=np.uint8)
+    assert lz.UncompressBlock(z, out) == len(src)
+    assert out.tobytes() == src
+
+
+@pytest.mark.parametrize("name", ["gettysburg.txt", "repeat.txt", "pg_control.tar",
+                                  "upperbound.data", "issue51.data", "random.data", "e.txt"])
+@pytest.mark.parametrize("depth", [0, 1, 10, 16, 512, 131072])
+def test_hc_byte_identical(name, depth, oracle):
+    import lz4_amd as lz
+    src = load(name)
+    for dst_len in (lz.CompressBlockBound(len(src)), len(src), int(len(src) * 0.4)):
+        assert _gpu_compress(lz, src, dst_len, depth) == _cpu_compress(oracle, src, dst_len, depth)
+
+
+def test_upperbound_short_dst_errors():
+    """TestCompressCornerCase_CopyDstUpperBound (block_test.go:117-151)."""
+    import lz4_amd as lz
+    src = load("upperbound.data")
+    dst = np.zeros(int(len(src) * 0.40), dtype=np.uint8)
+    with pytest.raises(lz.ErrInvalidSourceShortBuffer):
+        lz.CompressBlock(src, dst)
+    with pytest.raises(lz.ErrInvalidSourceShortBuffer):
+        lz.CompressBlockHC(src, dst, 16)
+
+
+def test_issue23(oracle):
+    """TestIssue23 (block_test.go:153-167)."""
+    import lz4_amd as lz
+    dst = np.zeros(lz.CompressBlockBound(1 << 16), dtype=np.uint8)
+    for j in range(1, 16):
+        buf = np.zeros(1 << 16, dtype=np.uint8)
+        buf[::j] = 1
+        n = lz.CompressBlock(buf, dst)
+        assert n <= 300
+        assert dst[:n].tobytes() == oracle.CompressBlock(buf)[1]
+
+
+def test_issue71(oracle):
+    """TestIssue71 (writer_test.go:201-231)."""
+    import lz4_amd as lz
+    for s in (b"abc", b"abcdefghijklmnopq"):
+        bound = lz.CompressBlockBound(len(s))
+        assert lz.CompressBlock(s, np.zeros(bound - 1, dtype=np.uint8)) == 0
+        d = np.zeros(bound, dtype=np.uint8)
+        n = lz.CompressBlock(s, d)
+        assert n > 0 and d[:n].tobytes() == oracle.CompressBlock(s)[1]
+
+
+def test_issue167():
+    """writer_test.go:192-199: must error, not overrun an 18-byte dst."""
+    import lz4_amd as lz
+    src = b"\xe300000000000000\t\x00\x00"
+    dst = np.zeros(18, dtype=np.uint8)
+    with pytest.raises(lz.ErrInvalidSourceShortBuffer):
+        lz.UncompressBlock(src, dst)
+
+
+def test_small_inputs_all_dst_sizes(oracle):
+    """Every (len, dst_len) corner of T5 on tiny inputs, Fast and HC."""
+    import lz4_amd as lz
+    rng = np.random.default_rng(7)
+    for n in (0, 1, 5, 13, 14, 15, 16, 17, 40, 200):
+        for alpha in (1, 3, 256):
+            src = rng.integers(0, alpha, n, dtype=np.uint8).tobytes()
+            for dst_len in sorted({0, 1, 2, n // 2, n, n + 1, lz.CompressBlockBound(n) - 1,
+                                   lz.CompressBlockBound(n)}):
+                for hc in (None, 7):
+                    assert _gpu_compress(lz, src, dst_len, hc) == _cpu_compress(oracle, src, dst_len, hc), \
+                        (n, alpha, dst_len, hc)
