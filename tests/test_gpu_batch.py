@@ -1,0 +1,153 @@
+"""GPU parity of the batched, device-resident hot path against the CPU oracle:
+per-block frame semantics (lz4stream/block.go:224-252,319-340), xxh32 block and
+content checksums, and frame assembly.  All calls go through the C ABI.
+Bit-exact bar for every byte, size word and checksum.
+"""
+import numpy as np
+import pytest
+
+from conftest import load
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    return torch
+
+
+def _dev(T, b):
+    a = np.frombuffer(bytes(b), dtype=np.uint8) if not isinstance(b, np.ndarray) else b
+    pad = T.zeros(a.size + 16, dtype=T.uint8, device="cuda")
+    pad[:a.size] = T.from_numpy(a.copy()).cuda()
+    return pad[:a.size]
+
+
+def _check_blocks(T, oracle, data, bs, level=0):
+    from lz4_amd import device as dev
+    src = _dev(T, data)
+    comp, res = dev.compress_blocks(src, bs, level)
+    pl, sw, xx = oracle.compress_blocks(data, bs, level, threads=8)
+    res_h = res.cpu().numpy()
+    comp_h = comp.cpu().numpy()
+    nb = len(sw)
+    assert res_h.shape[0] == nb
+    for b in range(nb):
+        raw = bool(sw[b] >> 31)
+        size = int(sw[b] & 0x7FFFFFFF)
+        if raw:
+            assert res_h[b] <= 0, (b, res_h[b])
+        else:
+            assert res_h[b] == size, (b, res_h[b], size)
+            assert comp_h[b, :size].tobytes() == pl[b, :size].tobytes(), b
+    got_xx = dev.xxh32_blocks(src, bs, nb).cpu().numpy().astype(np.uint32)
+    assert (got_xx == xx).all()
+    return src, comp, res, sw
+
+
+def test_cfg1_pg1661_64k_blocks(T, oracle):
+    """BASELINE config 1: pg1661.txt, Fast, 64 KiB blocks; candidate sum 366,553."""
+    data = load("pg1661.txt")
+    _, _, res, sw = _check_blocks(T, oracle, data, 1 << 16)
+    assert int((sw & 0x7FFFFFFF).sum()) == 366553 and int((sw >> 31).sum()) == 0
+
+
+@pytest.mark.parametrize("bs", [1 << 16, 1 << 18, 1 << 20, 1 << 22])
+@pytest.mark.parametrize("kind", ["mixed", "text", "binary"])
+def test_fast_blocks_synthetic(T, oracle, kind, bs):
+    """u16 table aliasing (T2) matters for blocks > 64 KiB: all four sizes."""
+    from lz4_amd import corpus
+    data = corpus.generate(kind, 3 * bs + 777, 5 * (1 << 20) + 12345)
+    _check_blocks(T, oracle, data, bs)
+
+
+@pytest.mark.parametrize("name", ["bzImage_lz4_isolated", "Mark.Twain-Tom.Sawyer.txt", "e.txt",
+                                  "random.data", "repeat.txt"])
+def test_fast_blocks_files(T, oracle, name):
+    _check_blocks(T, oracle, load(name), 1 << 18)
+
+
+@pytest.mark.parametrize("depth,bs", [(512, 1 << 16), (16, 1 << 18), (131072, 1 << 16)])
+def test_hc_blocks(T, oracle, depth, bs):
+    from lz4_amd import corpus
+    data = np.concatenate([corpus.generate("text", 99, 300000),
+                           np.frombuffer(load("pg_control.tar"), dtype=np.uint8),
+                           corpus.generate("random", 5, 70000)])
+    _check_blocks(T, oracle, data, bs, depth)
+
+
+def test_hc_level9_binary_1mb_block(T, oracle):
+    """cfg4 shape at test size: one 1 MiB block of bzImage, depth 131072."""
+    data = load("bzImage_lz4_isolated")[:1 << 20]
+    _check_blocks(T, oracle, data, 1 << 20, 131072)
+
+
+def test_decode_blocks_roundtrip_and_oracle(T, oracle):
+    from lz4_amd import corpus, device as dev
+    bs = 1 << 16
+    data = corpus.generate("mixed", 0, 3 * (1 << 20) + 4321)
+    src, comp, res, sw = _check_blocks(T, oracle, data, bs)
+    nb = len(sw)
+    off, sw_d = dev.frame_layout(res, len(data), bs, nb)
+    assert (sw_d.cpu().numpy().astype(np.uint32) == sw).all()
+    packed = T.zeros(int(off[nb].item()) + 16, dtype=T.uint8, device="cuda")
+    dev.frame_scatter(src, bs, comp, res, off, nb, packed)
+    out, out_len = dev.uncompress_blocks(packed, (off[:nb] + 4).contiguous(), sw_d, bs)
+    ol = out_len.cpu().numpy()
+    want_len = np.minimum(bs, len(data) - np.arange(nb) * bs)
+    assert (ol == want_len).all()
+    flat = np.concatenate([out[b, :ol[b]].cpu().numpy() for b in range(nb)])
+    assert flat.tobytes() == data.tobytes()
+
+
+def test_decode_errors_per_block_never_write_oob(T, oracle):
+    """TestDecodeBlockInvalid (decode_test.go:156-229) as one batch, guard bytes checked."""
+    from lz4_amd import device as dev
+    cases = [(b"\x00" * 6, 100), (b"\x00" * 100, 100), (b"\x20a", 100), (b"\x01", 10),
+             (b"\x1b0\x01\x00000000000000", 17), (b"\x000000", 10),
+             (b"\xe1abcdefghijklmn\x00\x00\xe0abcdefghijklmn", 40),
+             (b"\x50hello", 5), (b"\x50hello", 4)]
+    blob = b"".join(c for c, _ in cases)
+    offs = np.cumsum([0] + [len(c) for c, _ in cases[:-1]]).astype(np.int64)
+    lens = np.array([len(c) for c, _ in cases], dtype=np.int32)
+    stride = 128
+    for i, (c, dlen) in enumerate(cases):
+        out = T.full((1, stride), 0xAB, dtype=T.uint8, device="cuda")
+        o, ol = dev.uncompress_blocks(_dev(T, blob), T.tensor([offs[i]], device="cuda"),
+                                      T.tensor([lens[i]], dtype=T.int32, device="cuda"),
+                                      dlen, out=out, dst_stride=stride)
+        want, wd = oracle.decodeBlock(c, dlen)
+        got = int(ol[0].item())
+        assert (got < 0) == (want < 0), (i, got, want)
+        if want >= 0:
+            assert got == want and o[0, :got].cpu().numpy().tobytes() == wd[:want].tobytes()
+        assert bool((out[0, dlen:] == 0xAB).all().item()), "wrote beyond dst_len"
+
+
+@pytest.mark.parametrize("n", [0, 1, 65535, 65536, 65537, 3 * 65536, 1000000])
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 2 | 8, 3 | 8, 2 | 4])
+def test_frame_compress_device_vs_oracle(T, oracle, n, flags):
+    """Frame bytes incl. header, size words, zero-checksum elision, end mark,
+    content checksum and the ReadFrom trailing empty block (T8, T9)."""
+    from lz4_amd import corpus, device as dev
+    data = corpus.generate("mixed", 11, n) if n else np.zeros(0, dtype=np.uint8)
+    src = _dev(T, data)
+    got = dev.frame_compress(src, 1 << 16, flags, 0, content_size=n if flags & 4 else 0)
+    want = oracle.frame_compress(data, 1 << 16, flags, 0, content_size=n if flags & 4 else 0)
+    assert got.cpu().numpy().tobytes() == want
+
+
+def test_xxh32_stream_truncation_quirk(T, oracle):
+    """T6: Sum32 tests uint32(totalLen) >= 16 (xxh32zero.go:113-118)."""
+    from lz4_amd import device as dev
+    z = T.zeros((1 << 32) + 32, dtype=T.uint8, device="cuda")
+    z[(1 << 32):] = T.arange(32, dtype=T.uint8, device="cuda") + 1
+    n = (1 << 32) + 5
+    got = int(dev.xxh32_stream(z, n).item()) & 0xFFFFFFFF
+    h = oracle.XXHZero()
+    h.Write(np.arange(1, 6, dtype=np.uint8))  # the 5 buffered bytes
+    h.set_total_len(n)
+    assert got == h.Sum32()
+    # exact multiple of 2^32: hash of the empty string
+    assert (int(dev.xxh32_stream(z, 1 << 32).item()) & 0xFFFFFFFF) == 0x02CC5D05
