@@ -59,6 +59,12 @@ def load():
             raise ImportError(
                 "liblz4hip.so is not built: run `make -C lz4_amd/csrc` "
                 "(or __graft_entry__.build()); there is no CPU fallback")
+        # One HIP runtime per process: when torch is present its bundled
+        # libamdhip64 must be the one loaded first, or torch later finds no GPU.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)

@@ -1,0 +1,152 @@
+"""The reference's exact known answers, run through the HIP path via the C ABI
+(host-pointer entry points, i.e. what the cgo shim calls)."""
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+import kats
+from conftest import GOLDEN, load
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,src,exp", kats.DECODE, ids=[k[0] for k in kats.DECODE])
+def test_block_decode_kat(name, src, exp):
+    import lz4_amd as lz
+    dst = np.zeros(len(exp), dtype=np.uint8)
+    assert lz.UncompressBlock(src, dst) == len(exp)
+    assert dst.tobytes() == exp
+
+
+@pytest.mark.parametrize("name,src,size", kats.INVALID, ids=[k[0] for k in kats.INVALID])
+def test_block_decode_invalid(name, src, size):
+    import lz4_amd as lz
+    buf = (np.arange(size + 8) & 0xFF).astype(np.uint8)
+    if src == b"":  # T10: the API returns (0, nil) for an empty source (block.go:45-47)
+        assert lz.UncompressBlock(src, buf[:size]) == 0
+    else:
+        with pytest.raises(lz.ErrInvalidSourceShortBuffer):
+            lz.UncompressBlock(src, buf[:size])
+    assert (buf[size:] == (np.arange(size, size + 8) & 0xFF)).all()
+
+
+@pytest.mark.parametrize("src,dic,want", kats.WITH_DICT)
+def test_block_decode_with_dict(src, dic, want):
+    import lz4_amd as lz
+    dst = np.zeros(100, dtype=np.uint8)
+    if want is None:
+        with pytest.raises(lz.ErrInvalidSourceShortBuffer):
+            lz.UncompressBlockWithDict(src, dst, dic)
+    else:
+        n = lz.UncompressBlockWithDict(src, dst, dic)
+        assert dst[:n].tobytes() == want
+
+
+def test_fuzz_corpus_matches_oracle_and_stays_in_bounds(oracle):
+    import lz4_amd as lz
+    seeds = json.load(open(os.path.join(GOLDEN, "fuzz_uncompress_corpus.json")))
+    for name, hx in seeds.items():
+        src = bytes.fromhex(hx)
+        if not src:
+            continue
+        for size in (0, 16, 4096):
+            buf = (np.arange(size + 8) & 0xFF).astype(np.uint8)
+            want, wd = oracle.decodeBlock(src, size)
+            try:
+                n = lz.UncompressBlock(src, buf[:size])
+                assert want >= 0 and n == want and buf[:n].tobytes() == wd[:n].tobytes(), name
+            except lz.ErrInvalidSourceShortBuffer:
+                assert want < 0, name
+            assert (buf[size:] == (np.arange(size, size + 8) & 0xFF)).all(), name
+
+
+@pytest.mark.parametrize("want,data", kats.XXH32)
+def test_xxh32_kat(want, data):
+    import lz4_amd as lz
+    assert lz.ChecksumZero(data) == want
+
+
+def test_xxh32_unaligned_and_sizes(oracle):
+    import lz4_amd as lz
+    rng = np.random.default_rng(5)
+    blob = rng.integers(0, 256, 70000, dtype=np.uint8)
+    for n in (0, 1, 3, 4, 15, 16, 17, 63, 64, 65, 1000, 65536, 69999):
+        for off in (0, 1, 7):
+            b = blob[off:off + n].tobytes()
+            assert lz.ChecksumZero(b) == oracle.ChecksumZero(b)
+
+
+@pytest.mark.parametrize("frame", sorted(kats.GOLDEN_FRAMES))
+def test_golden_frames_decode_to_raw(frame):
+    """TestReader (reader_test.go:22-138): frames made by the C lz4 tool."""
+    import lz4_amd as lz
+    raw = load(kats.GOLDEN_FRAMES[frame][0])
+    assert lz.Reader(io.BytesIO(load(frame))).Read() == raw
+
+
+def test_malformed_block_checksum():
+    """reader_test.go: malformed.block.lz4 => invalid block checksum."""
+    import lz4_amd as lz
+    with pytest.raises(lz.ErrInvalidBlockChecksum):
+        lz.Reader(io.BytesIO(load("malformed.block.lz4"))).Read()
+
+
+def test_bad_header_checksum_and_magic():
+    import lz4_amd as lz
+    f = bytearray(load("gettysburg.txt.lz4"))
+    f[6] ^= 1
+    with pytest.raises(lz.ErrInvalidHeaderChecksum):
+        lz.Reader(io.BytesIO(bytes(f))).Read()
+    with pytest.raises(lz.ErrInvalidFrame):
+        lz.Reader(io.BytesIO(b"\x00\x01\x02\x03\x04\x05\x06\x07")).Read()
+    f = bytearray(load("gettysburg.txt.lz4"))
+    f[-1] ^= 1
+    with pytest.raises(lz.ErrInvalidFrameChecksum):
+        lz.Reader(io.BytesIO(bytes(f))).Read()
+
+
+@pytest.mark.parametrize("name", ["pg1661.txt", "random.data", "repeat.txt", "empty.txt",
+                                  "bzImage_lz4_isolated"])
+@pytest.mark.parametrize("opts", [dict(), dict(block_checksum=True), dict(content_size=123),
+                                  dict(block_size=1 << 16, block_checksum=True),
+                                  dict(block_size=1 << 18, content_checksum=False),
+                                  dict(block_size=1 << 16, readfrom=True),
+                                  dict(block_size=1 << 16, level=512)])
+def test_writer_frames_byte_identical_to_oracle(name, opts, oracle):
+    """TestWriter (writer_test.go:19-92) option matrix; compares the frame BYTES
+    with the oracle's Writer restatement, then reads it back."""
+    import lz4_amd as lz
+    if name == "bzImage_lz4_isolated" and opts.get("level"):
+        pytest.skip("HC on 1 MB binary is covered by test_gpu_batch at test size")
+    data = load(name)
+    w = io.BytesIO()
+    zw = lz.Writer(w)
+    zw.Apply(lz.BlockSizeOption(opts.get("block_size", 1 << 22)),
+             lz.BlockChecksumOption(opts.get("block_checksum", False)),
+             lz.ChecksumOption(opts.get("content_checksum", True)),
+             lz.SizeOption(opts.get("content_size", 0)),
+             lz.CompressionLevelOption(opts.get("level", 0)))
+    if opts.get("readfrom"):
+        zw.ReadFrom(io.BytesIO(data))
+    else:
+        zw.Write(data)
+    zw.Close()
+    flags = ((1 if opts.get("block_checksum") else 0) | (2 if opts.get("content_checksum", True) else 0)
+             | (4 if opts.get("content_size") else 0) | (8 if opts.get("readfrom") else 0))
+    want = oracle.frame_compress(data, opts.get("block_size", 1 << 22), flags, opts.get("level", 0),
+                                 opts.get("content_size", 0))
+    assert w.getvalue() == want
+    assert lz.Reader(io.BytesIO(w.getvalue())).Read() == data
+
+
+def test_flush_header_is_7_bytes():
+    """writer_test.go:243-246: an empty stream's header is exactly 7 bytes."""
+    import lz4_amd as lz
+    w = io.BytesIO()
+    zw = lz.Writer(w)
+    zw.Close()
+    assert len(w.getvalue()) == 7 + 4 + 4  # header + end mark + content checksum
+    assert w.getvalue()[7:] == b"\x00\x00\x00\x00\x05\x5d\xcc\x02"

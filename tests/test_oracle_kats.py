@@ -1,0 +1,260 @@
+"""Pins the CPU oracle against every exact known answer the reference's own tests
+hold for the hot path, and cross-checks its compressors against
+the second restatement (compressed bytes are NOT pinned by the reference:
+"parity unpinned" for the compress direction).  CPU only.
+"""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+import kats
+from conftest import GOLDEN, load
+from oracle import py_restatement as pyr
+from oracle import pyoracle as o
+
+
+# ---------------- decode: decode_test.go ----------------
+@pytest.mark.parametrize("name,src,exp", kats.DECODE, ids=[k[0] for k in kats.DECODE])
+def test_block_decode_kat(name, src, exp):
+    r, d = o.decodeBlock(src, len(exp))
+    assert r == len(exp)
+    assert d[:r].tobytes() == exp
+    assert pyr.decode(src, len(exp)) == exp
+
+
+@pytest.mark.parametrize("name,src,size", kats.INVALID, ids=[k[0] for k in kats.INVALID])
+def test_block_decode_invalid(name, src, size):
+    r, d = o.decodeBlock(src, size, guard=8)
+    assert r < 0
+    assert (d[size:] == (np.arange(size, size + 8) & 0xFF)).all(), "wrote out of bounds"
+    with pytest.raises(pyr.ShortBuffer):
+        pyr.decode(src, size)
+
+
+@pytest.mark.parametrize("src,dic,want", kats.WITH_DICT)
+def test_block_decode_with_dict(src, dic, want):
+    r, d = o.decodeBlock(src, 100, dic)
+    if want is None:
+        assert r < 0
+    else:
+        assert r == len(want) and d[:r].tobytes() == want
+        assert pyr.decode(src, 100, dic) == want
+
+
+def test_uncompress_empty_src_is_zero_nil():
+    """T10: block.go:45-47."""
+    assert o.UncompressBlock(b"", 10) == b""
+    assert o.decodeBlock(b"", 10)[0] < 0
+
+
+def test_issue167():
+    with pytest.raises(o.ErrInvalidSourceShortBuffer):
+        o.UncompressBlock(b"\xe300000000000000\t\x00\x00", 18)
+
+
+def test_long_lengths():
+    """TestLongLengths (decode_test.go:237-259): 16 MiB of 0xFF length bytes."""
+    n = (1 << 32) // 255
+    remain = (255 * n + 15) % (1 << 32)
+    src = b"\xf0" + b"\xff" * n + b"\x00" + bytes((65 + i) & 0xFF for i in range(remain))
+    assert o.decodeBlock(src, 2 * remain)[0] < 0
+
+
+def test_fuzz_corpus_never_writes_oob():
+    """fuzz/lz4.go:77-100 property on the checked-in decoder seeds."""
+    seeds = json.load(open(os.path.join(GOLDEN, "fuzz_uncompress_corpus.json")))
+    assert len(seeds) == 108
+    for name, hx in seeds.items():
+        src = bytes.fromhex(hx)
+        for size in (0, 1, 16, 100, 1 << 12):
+            r, d = o.decodeBlock(src, size, guard=8)
+            assert (d[size:] == (np.arange(size, size + 8) & 0xFF)).all(), name
+            try:
+                want = pyr.decode(src, size)
+                assert r == len(want) and d[:r].tobytes() == want, name
+            except pyr.ShortBuffer:
+                assert r < 0, name
+
+
+# ---------------- xxh32: xxh32zero_test.go ----------------
+@pytest.mark.parametrize("want,data", kats.XXH32)
+def test_xxh32_kat(want, data):
+    assert o.ChecksumZero(data) == want
+    h = o.XXHZero()
+    h.Write(data)
+    assert h.Sum32() == want
+    h = o.XXHZero()  # TestZeroSplitData
+    h.Write(data[:len(data) // 2])
+    h.Write(data[len(data) // 2:])
+    assert h.Sum32() == want
+
+
+def test_xxh32_matches_python_xxhash_on_random():
+    xxhash = pytest.importorskip("xxhash")
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 15, 16, 17, 31, 32, 33, 1000, 65536, 100003):
+        b = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert o.ChecksumZero(b) == xxhash.xxh32(b, seed=0).intdigest()
+        h = o.XXHZero()
+        for i in range(0, n, 7):
+            h.Write(b[i:i + 7])
+        assert h.Sum32() == xxhash.xxh32(b, seed=0).intdigest()
+
+
+def test_xxh32_streaming_truncation_quirk():
+    """T6 (xxh32zero.go:113-118): len = 2^32*k + r, r < 16 takes the short branch."""
+    h = o.XXHZero()
+    h.Write(b"abcde")
+    h.set_total_len((1 << 32) + 5)
+    short = o.XXHZero()
+    short.Write(b"abcde")
+    assert h.Sum32() == short.Sum32() == o.ChecksumZero(b"abcde")
+    h = o.XXHZero()
+    h.set_total_len(1 << 37)  # 128 GiB exactly (cfg5)
+    assert h.Sum32() == 0x02CC5D05
+
+
+# ---------------- frame: frame_test.go, reader_test.go ----------------
+@pytest.mark.parametrize("bs,want", kats.HEADERS)
+def test_frame_descriptor_bytes(bs, want):
+    hdr = o.frame_header(bs, o.F_CONTENT_CHECKSUM)
+    assert hdr[:4] == b"\x04\x22\x4d\x18" and hdr[4:] == want and len(hdr) == 7
+
+
+@pytest.mark.parametrize("frame", sorted(kats.GOLDEN_FRAMES))
+def test_golden_frames_decode_to_raw(frame):
+    raw_name, cs = kats.GOLDEN_FRAMES[frame]
+    raw = load(raw_name)
+    assert o.frame_uncompress(load(frame), len(raw) + 16) == raw
+    if cs is not None:
+        assert o.ChecksumZero(raw) == cs
+
+
+def test_legacy_frame_is_rejected_for_now():
+    with pytest.raises(ValueError) as e:
+        o.frame_uncompress(load(kats.LEGACY_FRAME), 1 << 21)
+    assert e.value.args[0] == -2  # LZ4O_FE_INVALID_FRAME
+
+
+def test_malformed_block_checksum():
+    with pytest.raises(ValueError) as e:
+        o.frame_uncompress(load("malformed.block.lz4"), 1 << 22)
+    assert e.value.args[0] == -5  # LZ4O_FE_BLOCK_CHECKSUM
+
+
+@pytest.mark.parametrize("n", [0, 1, 100, 65536, 65537, 200000])
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 2 | 8, 3 | 8, 2 | 4])
+@pytest.mark.parametrize("level", [0, 512])
+def test_frame_roundtrip_and_shape(n, flags, level):
+    rng = np.random.default_rng(n + flags)
+    data = (rng.integers(0, 4, n, dtype=np.uint8) * 17).tobytes()
+    f = o.frame_compress(data, 1 << 16, flags, level, content_size=n if flags & 4 else 0)
+    assert o.frame_uncompress(f, n + 16) == data
+    if flags & 8 and n % 65536 == 0:
+        # T9: trailing zero-length raw block (+ xxh32("") when block checksums are on)
+        tail = b"\x00\x00\x00\x80" + (b"\x05\x5d\xcc\x02" if flags & 1 else b"")
+        end = 4 + (4 if flags & 2 else 0)
+        assert f[:-end].endswith(tail)
+    # independent decoder: the system C lz4 library, when present
+    try:
+        l4 = ctypes.CDLL("liblz4.so.1")
+    except OSError:
+        return
+    if not flags & 1:  # T7: block checksums cover uncompressed bytes => only self-compatible
+        dctx = ctypes.c_void_p()
+        assert l4.LZ4F_createDecompressionContext(ctypes.byref(dctx), 100) == 0
+        out = ctypes.create_string_buffer(n + 16)
+        dsz, ssz = ctypes.c_size_t(n + 16), ctypes.c_size_t(len(f))
+        l4.LZ4F_decompress.restype = ctypes.c_size_t
+        rc = l4.LZ4F_decompress(dctx, out, ctypes.byref(dsz), f, ctypes.byref(ssz), None)
+        l4.LZ4F_freeDecompressionContext(dctx)
+        assert rc == 0 and out.raw[:dsz.value] == data
+
+
+# ---------------- compressors: block_test.go inequalities + differential ----------------
+@pytest.mark.parametrize("name", sorted(kats.CANDIDATE_SIZES))
+def test_candidate_sizes_and_roundtrip(name):
+    src = load(name)
+    fast, hc512, hc9 = kats.CANDIDATE_SIZES[name]
+    n, z = o.CompressBlock(src)
+    assert n == fast
+    assert o.UncompressBlock(z, len(src)) == src
+    if hc512 is not None:
+        assert o.CompressBlockHC(src, 512)[0] == hc512
+        n9, z9 = o.CompressBlockHC(src, 131072)
+        assert n9 == hc9 and o.UncompressBlock(z9, len(src)) == src
+    l4 = ctypes.CDLL("liblz4.so.1")  # independent decoder: output is legal LZ4
+    out = ctypes.create_string_buffer(len(src) + 1)
+    assert l4.LZ4_decompress_safe(z, out, len(z), len(src)) == len(src)
+    assert out.raw[:len(src)] == src
+
+
+def test_cfg1_pg1661_64k():
+    pl, sw, xx = o.compress_blocks(load("pg1661.txt"), 1 << 16)
+    assert len(sw) == 10 and int((sw & 0x7FFFFFFF).sum()) == 366553 and not (sw >> 31).any()
+
+
+def test_issue23_issue71_issue116_upperbound():
+    for j in range(1, 16):
+        buf = np.zeros(1 << 16, dtype=np.uint8)
+        buf[::j] = 1
+        assert o.CompressBlock(buf)[0] <= 300
+    for s in (b"abc", b"abcdefghijklmnopq"):
+        b = o.CompressBlockBound(len(s))
+        assert o.CompressBlock(s, b - 1)[0] == 0 and o.CompressBlock(s, b)[0] > 0
+    src = load("pg1661.txt")
+    with pytest.raises(o.ErrInvalidSourceShortBuffer):
+        o.CompressBlock(src, len(src) - len(src) // 2)
+    up = load("upperbound.data")
+    for f in (lambda: o.CompressBlock(up, int(len(up) * 0.4)),
+              lambda: o.CompressBlockHC(up, 16, int(len(up) * 0.4))):
+        with pytest.raises(o.ErrInvalidSourceShortBuffer):
+            f()
+
+
+def _both(src, dst_len, hc):
+    try:
+        a = (o.CompressBlockHC(src, hc, dst_len) if hc is not None else o.CompressBlock(src, dst_len))[1]
+    except o.ErrInvalidSourceShortBuffer:
+        a = "ERR"
+    try:
+        b = pyr.compress_hc(src, hc, dst_len) if hc is not None else pyr.compress_fast(src, dst_len)
+    except pyr.ShortBuffer:
+        b = "ERR"
+    return a, b
+
+
+@pytest.mark.parametrize("name", ["gettysburg.txt", "repeat.txt", "random.data", "pg_control.tar",
+                                  "upperbound.data", "issue51.data", "e.txt"])
+def test_two_restatements_agree_on_files(name):
+    src = load(name)
+    for dst_len in (None, len(src), len(src) // 2, int(len(src) * 0.4), 10):
+        for hc in (None, 1, 16, 512):
+            a, b = _both(src, dst_len, hc)
+            assert a == b, (name, dst_len, hc)
+
+
+def test_two_restatements_agree_beyond_64k():
+    """T2 (u16 aliasing) only shows in blocks > 64 KiB."""
+    src = load("pg1661.txt")[:200000]
+    a, b = _both(src, None, None)
+    assert a == b
+    src = load("bzImage_lz4_isolated")[300000:480000]
+    assert _both(src, None, None)[0] == _both(src, None, None)[1]
+    a, b = _both(src[:90000], None, 64)
+    assert a == b
+
+
+def test_two_restatements_agree_on_random_small():
+    rng = np.random.default_rng(11)
+    for _ in range(150):
+        n = int(rng.choice([0, 1, 5, 13, 14, 15, 16, 17, 30, 100, 1000, 4000]))
+        alpha = int(rng.choice([1, 2, 4, 16, 256]))
+        src = rng.integers(0, alpha, n, dtype=np.uint8).tobytes()
+        for dst_len in (None, n, n // 2, 3, 0):
+            for hc in (None, 7):
+                a, b = _both(src, dst_len, hc)
+                assert a == b, (n, alpha, dst_len, hc)
