@@ -114,6 +114,14 @@ int lz4hip_xxh32_blocks(const void *d_base, size_t n, size_t stride, const uint6
  * one wave walks the n bytes.  Writes one uint32 to d_out. */
 int lz4hip_xxh32_stream(const void *d_src, size_t n, uint32_t *d_out, void *stream);
 
+/* The same checksum for a stream cut across GPUs (block-range shards): the
+ * XXHZero state {v1,v2,v3,v4,totalLen lo,hi} (6 x u32 in d_state) is carried
+ * from shard to shard in stream order.  first != 0 starts from Reset()
+ * (xxh32zero.go:37-44); every non-final piece must be a multiple of 16 bytes
+ * (block sizes are); final_piece != 0 also writes Sum32() to d_digest. */
+int lz4hip_xxh32_stream_update(const void *d_src, size_t n, uint32_t *d_state, int first,
+                               int final_piece, uint32_t *d_digest, void *stream);
+
 /* Frame assembly on device: FrameDescriptor.Write (frame.go:144-167),
  * FrameDataBlock.Write per block (lz4stream/block.go:254-276: size word,
  * payload or raw src when d_result[b] <= 0, checksum word unless 0) and

@@ -29,6 +29,7 @@ SYMBOLS = {
     "lz4hip_uncompress_blocks": (_int, [_vp, _vp, _vp, _sz, _vp, _sz, _u32, _vp, _vp]),
     "lz4hip_xxh32_blocks": (_int, [_vp, _sz, _sz, _vp, _vp, _sz, _vp, _vp]),
     "lz4hip_xxh32_stream": (_int, [_vp, _sz, _vp, _vp]),
+    "lz4hip_xxh32_stream_update": (_int, [_vp, _sz, _vp, _int, _int, _vp, _vp]),
     "lz4hip_frame_layout": (_int, [_vp, _sz, _u32, _sz, _vp, _u64, _vp, _vp, _vp]),
     "lz4hip_frame_scatter": (_int, [_vp, _sz, _u32, _vp, _sz, _vp, _vp, _vp, _sz, _vp, _u64, _vp]),
     "lz4hip_frame_header": (_sz, [_vp, _u32, _u32, _u64]),

@@ -171,6 +171,17 @@ int lz4hip_xxh32_stream(const void *d_src, size_t n, uint32_t *d_out, void *stre
     return LZ4HIP_OK;
 }
 
+int lz4hip_xxh32_stream_update(const void *d_src, size_t n, uint32_t *d_state, int first,
+                               int final_piece, uint32_t *d_digest, void *stream) {
+    if (!d_state || (!d_src && n) || (final_piece && !d_digest))
+        return fail(LZ4HIP_ERR_ARG, "null pointer");
+    if (!final_piece && (n & 15))
+        return fail(LZ4HIP_ERR_ARG, "a non-final piece must be a multiple of 16 bytes");
+    HIPCHK(launch_xxh32_update((const uint8_t *)d_src, n, d_state, first, final_piece, d_digest,
+                               (hipStream_t)stream));
+    return LZ4HIP_OK;
+}
+
 int lz4hip_frame_layout(const int32_t *d_result, size_t n, uint32_t block_size, size_t n_blocks,
                         const uint32_t *d_block_xxh, uint64_t first_off, uint64_t *d_entry_off,
                         uint32_t *d_size_words, void *stream) {

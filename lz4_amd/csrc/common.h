@@ -74,6 +74,8 @@ hipError_t launch_decode(const uint8_t *src, const uint64_t *off, const uint32_t
 hipError_t launch_xxh32_blocks(const uint8_t *base, size_t n, size_t stride, const uint64_t *off,
                                const int32_t *len, size_t n_spans, uint32_t *out, hipStream_t st);
 hipError_t launch_xxh32_stream(const uint8_t *src, size_t n, uint32_t *out, hipStream_t st);
+hipError_t launch_xxh32_update(const uint8_t *src, size_t n, uint32_t *state, int first,
+                               int final_piece, uint32_t *digest, hipStream_t st);
 hipError_t launch_frame_layout(const int32_t *result, size_t n, uint32_t bs, size_t nb,
                                const uint32_t *xxh, uint64_t first_off, uint64_t *entry_off,
                                uint32_t *size_words, hipStream_t st);

@@ -112,6 +112,54 @@ __global__ __launch_bounds__(64) void k_xxh32_stream(const uint8_t *__restrict__
     out[0] = h;
 }
 
+// Chained form of the content checksum for a stream cut across GPUs: state =
+// {v1, v2, v3, v4, totalLen lo, totalLen hi}.  Non-final pieces must be multiples
+// of 16 bytes (block sizes are), so no carry buffer travels (xxh32zero.go:58-86).
+__global__ __launch_bounds__(64) void k_xxh32_update(const uint8_t *__restrict__ src, size_t n,
+                                                     uint32_t *__restrict__ state, int first,
+                                                     int final_piece,
+                                                     uint32_t *__restrict__ digest) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t v1, v2, v3, v4;
+    uint64_t total;
+    if (first) {  // Reset(): xxh32zero.go:37-44
+        v1 = P1 + P2; v2 = P2; v3 = 0; v4 = 0u - P1; total = 0;
+    } else {
+        v1 = state[0]; v2 = state[1]; v3 = state[2]; v4 = state[3];
+        total = (uint64_t)state[4] | ((uint64_t)state[5] << 32);
+    }
+    const size_t stripes = n / 16;
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const uint4 *q = reinterpret_cast<const uint4 *>(src);
+        for (size_t k = 0; k < stripes; k++) {
+            const uint4 a = q[k];
+            v1 = xround(v1, a.x); v2 = xround(v2, a.y); v3 = xround(v3, a.z); v4 = xround(v4, a.w);
+        }
+    } else {
+        for (size_t k = 0; k < stripes; k++) {
+            const uint8_t *p = src + k * 16;
+            v1 = xround(v1, ld32(p)); v2 = xround(v2, ld32(p + 4));
+            v3 = xround(v3, ld32(p + 8)); v4 = xround(v4, ld32(p + 12));
+        }
+    }
+    total += n;
+    state[0] = v1; state[1] = v2; state[2] = v3; state[3] = v4;
+    state[4] = (uint32_t)total; state[5] = (uint32_t)(total >> 32);
+    if (final_piece) {  // Sum32(): xxh32zero.go:112-139 incl. the uint32 truncation
+        uint32_t h = (uint32_t)total;
+        if (h >= 16) h += rol(v1, 1) + rol(v2, 7) + rol(v3, 12) + rol(v4, 18);
+        else h += P5;
+        digest[0] = xtail(h, src + stripes * 16, n - stripes * 16);
+    }
+}
+
+hipError_t launch_xxh32_update(const uint8_t *src, size_t n, uint32_t *state, int first,
+                               int final_piece, uint32_t *digest, hipStream_t st) {
+    hipLaunchKernelGGL(k_xxh32_update, dim3(1), dim3(kWave), 0, st, src, n, state, first,
+                       final_piece, digest);
+    return hipGetLastError();
+}
+
 hipError_t launch_xxh32_blocks(const uint8_t *base, size_t n, size_t stride, const uint64_t *off,
                                const int32_t *len, size_t n_spans, uint32_t *out,
                                hipStream_t st) {

@@ -98,6 +98,16 @@ def xxh32_stream(src, n=None):
     return out
 
 
+def xxh32_stream_update(src, n, state, first, final):
+    """Chained content checksum over block-range shards; state: int32[6] on device.
+    Returns the digest tensor (int32[1]) when final, else None."""
+    digest = torch.empty(1, dtype=torch.int32, device=state.device) if final else None
+    _lib.check(_lib.load().lz4hip_xxh32_stream_update(
+        src.data_ptr() if n else None, n, state.data_ptr(), int(first), int(final),
+        digest.data_ptr() if final else None, _stream_ptr()))
+    return digest
+
+
 def frame_layout(result, n, block_size, nb, block_xxh=None, first_off=0):
     """Exclusive scan of entry sizes (lz4stream/block.go:254-276).
     Returns (entry_off [nb+1] int64, size_words [nb] int32)."""

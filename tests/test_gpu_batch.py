@@ -151,3 +151,40 @@ def test_xxh32_stream_truncation_quirk(T, oracle):
     assert got == h.Sum32()
     # exact multiple of 2^32: hash of the empty string
     assert (int(dev.xxh32_stream(z, 1 << 32).item()) & 0xFFFFFFFF) == 0x02CC5D05
+
+
+def test_sharded_frame_path_world1_device_ops(T, oracle):
+    """lz4_amd.shard with the real device ops (world size 1, RCCL backend):
+    exercises lz4hip_xxh32_stream_update and span assembly on the GPU."""
+    import os
+
+    import torch.distributed as dist
+
+    from lz4_amd import corpus, shard
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29611")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=T.device("cuda", 0))
+    try:
+        for n, flags in ((5 * 65536 + 999, 3), (4 * 65536, 3 | 8), (0, 2)):
+            data = corpus.generate("mixed", 5, n) if n else np.zeros(0, dtype=np.uint8)
+            frame = shard.frame_compress_sharded(_dev(T, data), n, 1 << 16, flags, 0)
+            assert frame.cpu().numpy().tobytes() == oracle.frame_compress(data, 1 << 16, flags, 0)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def test_xxh32_stream_update_chain(T, oracle):
+    from lz4_amd import corpus, device as dev
+    data = corpus.generate("text", 1, 300001)
+    src = _dev(T, data)
+    state = T.zeros(6, dtype=T.int32, device="cuda")
+    cuts = [0, 65536, 65536 * 3, 300001]
+    d = None
+    for i in range(3):
+        piece = src[cuts[i]:cuts[i + 1]]
+        d = dev.xxh32_stream_update(piece, piece.numel(), state, i == 0, i == 2)
+    assert (int(d.item()) & 0xFFFFFFFF) == oracle.ChecksumZero(data)
+    assert (int(dev.xxh32_stream(src).item()) & 0xFFFFFFFF) == oracle.ChecksumZero(data)
