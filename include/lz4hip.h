@@ -78,8 +78,14 @@ size_t lz4hip_compress_bound(size_t n);
 
 /* Fast level: (*Compressor).CompressBlock, internal/lz4block/block.go:105-295,
  * as called per block by FrameDataBlock.Compress, lz4stream/block.go:232-234. */
+/* d_workspace (optional): lz4hip_fast_workspace_bytes(n_blocks) bytes, 16-byte
+ * aligned.  With a workspace the hash tables live in global memory (L2 /
+ * Infinity-Cache resident) and many wavefronts per CU run; with NULL each table
+ * lives in LDS, one block per CU.  The output bytes are the same. */
+size_t lz4hip_fast_workspace_bytes(size_t n_blocks);
 int lz4hip_compress_fast_blocks(const void *d_src, size_t n, uint32_t block_size, int dst_mode,
-                                void *d_dst, size_t dst_stride, int32_t *d_result, void *stream);
+                                void *d_dst, size_t dst_stride, int32_t *d_result,
+                                void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* HC level: (*CompressorHC).CompressBlock, internal/lz4block/block.go:319-481,
  * lz4stream/block.go:235-237.  depth = chain depth (0 => 65536); the frame path

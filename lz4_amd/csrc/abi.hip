@@ -3,6 +3,7 @@
 // Device entry points validate shapes on the host before any launch (a faulting
 // kernel can reset the whole node) and are asynchronous.  Host-pointer entry
 // points own their device buffers for the duration of the call.
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -45,6 +46,8 @@ int block_size_index(uint32_t bs) {  // blocks.go:22-36
 }
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+constexpr size_t kFastSlots = 8192;             // resident waves of the global-table Fast kernel
+constexpr size_t kFastSlotBytes = 65536 * 2;    // one u16 table
 constexpr size_t kHcSlots = 2048;               // resident workgroups of the HC kernel
 constexpr size_t kHcSlotBytes = 2 * 65536 * 4;  // hashTable + chainTable
 constexpr size_t kMaxSingleBlock = 1u << 30;    // int32 positions inside a block
@@ -66,6 +69,23 @@ uint32_t host_xxh32_short(const uint8_t *p, size_t n) {  // n < 16
     h *= 3266489917u;
     h ^= h >> 16;
     return h;
+}
+
+// Kernel generation of the Fast compressor: 2 = window-parallel (fast2.hip, default),
+// 1 = step-serial (fast.hip).  LZ4HIP_FAST=1 selects the older kernel for A/B runs.
+int fast_generation() {
+    static const int g = [] {
+        const char *e = getenv("LZ4HIP_FAST");
+        return (e && e[0] == '1') ? 1 : 2;
+    }();
+    return g;
+}
+hipError_t launch_fast_any(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
+                           uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,
+                           uint16_t *ws, size_t slots, hipStream_t st) {
+    return fast_generation() == 1
+               ? launch_fast(src, n, bs, nb, dst_mode, dst_len_x, dst, dst_stride, result, ws, slots, st)
+               : launch_fast2(src, n, bs, nb, dst_mode, dst_len_x, dst, dst_stride, result, ws, slots, st);
 }
 
 // RAII device buffer for the host-pointer entry points.
@@ -93,8 +113,13 @@ int lz4hip_device_count(void) {
 
 size_t lz4hip_compress_bound(size_t n) { return n + n / 255 + 16; }
 
+size_t lz4hip_fast_workspace_bytes(size_t n_blocks) {
+    return (n_blocks < kFastSlots ? (n_blocks ? n_blocks : 1) : kFastSlots) * kFastSlotBytes;
+}
+
 int lz4hip_compress_fast_blocks(const void *d_src, size_t n, uint32_t block_size, int dst_mode,
-                                void *d_dst, size_t dst_stride, int32_t *d_result, void *stream) {
+                                void *d_dst, size_t dst_stride, int32_t *d_result,
+                                void *d_workspace, size_t workspace_bytes, void *stream) {
     if (!valid_block_size(block_size)) return fail(LZ4HIP_ERR_ARG, "invalid block size");
     if (dst_mode != LZ4HIP_DST_FRAME && dst_mode != LZ4HIP_DST_BOUND)
         return fail(LZ4HIP_ERR_ARG, "invalid dst_mode");
@@ -106,8 +131,13 @@ int lz4hip_compress_fast_blocks(const void *d_src, size_t n, uint32_t block_size
         dst_mode == LZ4HIP_DST_FRAME ? block_size : lz4hip_compress_bound(block_size);
     if (dst_stride < need) return fail(LZ4HIP_ERR_ARG, "dst_stride smaller than dst_len");
     const size_t nb = (n + block_size - 1) / block_size;
-    HIPCHK(launch_fast((const uint8_t *)d_src, n, block_size, nb, dst_mode, 0, (uint8_t *)d_dst,
-                       dst_stride, d_result, (hipStream_t)stream));
+    size_t slots = d_workspace ? workspace_bytes / kFastSlotBytes : 0;
+    if (slots > kFastSlots) slots = kFastSlots;
+    if (d_workspace && (!aligned16(d_workspace) || slots == 0))
+        return fail(LZ4HIP_ERR_ARG, "workspace unaligned or smaller than one table");
+    HIPCHK(launch_fast_any((const uint8_t *)d_src, n, block_size, nb, dst_mode, 0, (uint8_t *)d_dst,
+                       dst_stride, d_result, (uint16_t *)d_workspace, slots,
+                       (hipStream_t)stream));
     return LZ4HIP_OK;
 }
 
@@ -261,8 +291,8 @@ static int64_t compress_one(const uint8_t *src, size_t n, uint8_t *dst, size_t d
                          d_dst.as<uint8_t>(), 0, d_res.as<int32_t>(), d_ws.as<uint32_t>(), 1,
                          nullptr));
     } else {
-        HIPCHK(launch_fast(d_src.as<uint8_t>(), n, bs, 1, kDstExplicit, (uint32_t)dst_len,
-                           d_dst.as<uint8_t>(), 0, d_res.as<int32_t>(), nullptr));
+        HIPCHK(launch_fast_any(d_src.as<uint8_t>(), n, bs, 1, kDstExplicit, (uint32_t)dst_len,
+                           d_dst.as<uint8_t>(), 0, d_res.as<int32_t>(), nullptr, 0, nullptr));
     }
     int32_t r = 0;
     HIPCHK(hipMemcpy(&r, d_res.p, sizeof r, hipMemcpyDeviceToHost));
@@ -393,8 +423,9 @@ int64_t lz4hip_frame_compress(const uint8_t *src, size_t n, uint32_t block_size,
         if (csum) STEP(launch_xxh32_stream(d_src.as<uint8_t>(), n, d_cs.as<uint32_t>(), s_sum));
         if (nb_data) {
             if (level == 0) {
-                STEP(launch_fast(d_src.as<uint8_t>(), n, block_size, nb_data, LZ4HIP_DST_FRAME, 0,
-                                 d_comp.as<uint8_t>(), block_size, d_res.as<int32_t>(), s_main));
+                STEP(launch_fast_any(d_src.as<uint8_t>(), n, block_size, nb_data, LZ4HIP_DST_FRAME, 0,
+                                 d_comp.as<uint8_t>(), block_size, d_res.as<int32_t>(), nullptr, 0,
+                                 s_main));
             } else {
                 DevBuf d_ws;
                 const size_t slots = nb_data < kHcSlots ? nb_data : kHcSlots;

@@ -25,26 +25,16 @@ __device__ __forceinline__ bool fast_ok(const uint8_t *s, int pos, int ref, uint
     return offset > 0 && offset < kWinSize && word == ld32(s + ref);
 }
 
-__global__ __launch_bounds__(64) void k_fast_compress(const uint8_t *__restrict__ src,
-                                                      size_t n_total, uint32_t block_size,
-                                                      int dst_mode, uint32_t dst_len_x, uint8_t *__restrict__ dst,
-                                                      size_t dst_stride,
-                                                      int32_t *__restrict__ result) {
-    __shared__ uint16_t table[1 << 16];
-    const int lane = lane_id();
-    const size_t b = blockIdx.x;
-    const uint8_t *s = src + b * (size_t)block_size;
-    const size_t start = b * (size_t)block_size;
-    const size_t left = n_total > start ? n_total - start : 0;
-    const int n = (int)(left < block_size ? left : block_size);
-    uint8_t *d = dst + b * dst_stride;
+// One block, one wavefront.  `table` is 65536 x u16, zeroed by the caller's wave here;
+// it may live in LDS or in global memory (same-wave accesses are ordered either way).
+template <typename TablePtr>
+__device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const int n,
+                                          uint8_t *__restrict__ d, const int dlen,
+                                          TablePtr table, const int lane) {
     const int bound = (int)compress_bound32((uint32_t)n);
-    const int dlen = dst_mode == LZ4HIP_DST_FRAME ? n
-                         : dst_mode == LZ4HIP_DST_BOUND ? bound : (int)dst_len_x;
     const bool not_compressible = dlen < bound;  // block.go:110
-
     {  // reset(): block.go:94,107
-        uint4 *t4 = reinterpret_cast<uint4 *>(table);
+        uint4 *t4 = (uint4 *)(table);
         for (int k = lane; k < (1 << 16) * 2 / 16; k += kWave) t4[k] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
@@ -193,15 +183,67 @@ __global__ __launch_bounds__(64) void k_fast_compress(const uint8_t *__restrict_
             ret = di + l_len;
         }
     }
-    if (lane == 0) result[b] = ret;
+    return ret;
+}
+
+__device__ __forceinline__ int block_dlen(int dst_mode, int n, uint32_t dst_len_x) {
+    return dst_mode == LZ4HIP_DST_FRAME  ? n
+           : dst_mode == LZ4HIP_DST_BOUND ? (int)compress_bound32((uint32_t)n)
+                                          : (int)dst_len_x;
+}
+
+// Variant A: table in LDS, one workgroup (= one wave) per block, one block per CU.
+__global__ __launch_bounds__(64) void k_fast_compress(const uint8_t *__restrict__ src,
+                                                      size_t n_total, uint32_t block_size,
+                                                      int dst_mode, uint32_t dst_len_x,
+                                                      uint8_t *__restrict__ dst,
+                                                      size_t dst_stride,
+                                                      int32_t *__restrict__ result) {
+    __shared__ uint16_t table[1 << 16];
+    const int lane = lane_id();
+    const size_t b = blockIdx.x;
+    const size_t start = b * (size_t)block_size;
+    const size_t left = n_total > start ? n_total - start : 0;
+    const int n = (int)(left < block_size ? left : block_size);
+    const int r = fast_block(src + start, n, dst + b * dst_stride,
+                             block_dlen(dst_mode, n, dst_len_x), table, lane);
+    if (lane == 0) result[b] = r;
+}
+
+// Variant B: table in a global-memory slot per resident wave (stays in L2 / the
+// Infinity Cache), many waves per CU hide the dependent-load latency of the walk.
+__global__ __launch_bounds__(64) void k_fast_compress_gtab(const uint8_t *__restrict__ src,
+                                                           size_t n_total, uint32_t block_size,
+                                                           size_t nb, int dst_mode,
+                                                           uint32_t dst_len_x,
+                                                           uint8_t *__restrict__ dst,
+                                                           size_t dst_stride,
+                                                           int32_t *__restrict__ result,
+                                                           uint16_t *__restrict__ ws) {
+    const int lane = lane_id();
+    uint16_t *table = ws + (size_t)blockIdx.x * (1 << 16);
+    for (size_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const size_t start = b * (size_t)block_size;
+        const size_t left = n_total > start ? n_total - start : 0;
+        const int n = (int)(left < block_size ? left : block_size);
+        const int r = fast_block(src + start, n, dst + b * dst_stride,
+                                 block_dlen(dst_mode, n, dst_len_x), table, lane);
+        if (lane == 0) result[b] = r;
+    }
 }
 
 hipError_t launch_fast(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
-                       uint32_t dst_len_x, uint8_t *dst,
-                       size_t dst_stride, int32_t *result, hipStream_t st) {
+                       uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,
+                       uint16_t *ws, size_t slots, hipStream_t st) {
     if (nb == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_fast_compress, dim3((unsigned)nb), dim3(kWave), 0, st, src, n, bs,
-                       dst_mode, dst_len_x, dst, dst_stride, result);
+    if (ws && slots) {
+        const size_t grid = nb < slots ? nb : slots;
+        hipLaunchKernelGGL(k_fast_compress_gtab, dim3((unsigned)grid), dim3(kWave), 0, st, src, n,
+                           bs, nb, dst_mode, dst_len_x, dst, dst_stride, result, ws);
+    } else {
+        hipLaunchKernelGGL(k_fast_compress, dim3((unsigned)nb), dim3(kWave), 0, st, src, n, bs,
+                           dst_mode, dst_len_x, dst, dst_stride, result);
+    }
     return hipGetLastError();
 }
 

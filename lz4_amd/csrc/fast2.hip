@@ -1,0 +1,454 @@
+// fast2.hip -- window-parallel Fast (greedy) LZ4 block compressor for gfx950.
+//
+// Same parse as (*Compressor).CompressBlock (internal/lz4block/block.go:105-295),
+// so the same bytes, but organised for a 64-lane wavefront:
+//
+//   Phase A (64 lanes, one per source position of a 64-byte window): hash6
+//   (block.go:35-38), table lookup, candidate address by the rule of get()
+//   (block.go:74-86), 4-byte verify, and the first 16 bytes of forward / 8 bytes
+//   of backward match extension (block.go:170-193) -- all speculative, against
+//   the table as it stood when the window was opened.
+//
+//   Phase B (wave-uniform walk): replays the reference's step sequence over the
+//   window using the per-lane answers.  A lane's speculative answer is exact
+//   unless a position put() since the window opened has the same hash; a small
+//   LDS tag table flags the lanes that may be affected and an exact ballot
+//   resolves them (the newer candidate is then a window lane itself).  Puts,
+//   the get/put order of block.go:134-155, the adaptive skip (:159) and the
+//   emission (:195-248) follow the reference step by step.
+//
+// The memory round trips of the serial walk (table load -> candidate load ->
+// extension loads, per step) become three gathers per 64 positions.
+#include "common.h"
+
+namespace lz4hip {
+
+constexpr int kTagN = 1024;  // LDS tag slots per wave (u32 each)
+
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+
+// Cooperative backward extension from `back` (block.go:170-177), 64 bytes per round.
+__device__ __forceinline__ int ext_backward(const uint8_t *s, int found, int ref, int back,
+                                            int maxb, int lane) {
+    while (back < maxb) {
+        const int k = back + lane;
+        const bool eq = k < maxb && s[found - 1 - k] == s[ref - 1 - k];
+        const uint64_t stop = ballot(!eq);
+        if (stop == 0) {
+            back += kWave;
+            continue;
+        }
+        back += __builtin_ctzll(stop);
+        break;
+    }
+    return back < maxb ? back : maxb;
+}
+
+// Cooperative forward extension from si (block.go:184-193): 8-byte strides while si+8 <= sn.
+__device__ __forceinline__ int ext_forward(const uint8_t *s, int si, int offset, int sn, int lane) {
+    for (;;) {
+        const int p = si + 8 * lane;
+        const bool valid = p + 8 <= sn;
+        uint64_t x = 0;
+        if (valid) x = ld64(s + p) ^ ld64(s + p - offset);
+        const uint64_t stop = ballot(!valid || x != 0);
+        if (stop == 0) {
+            si += 8 * kWave;
+            continue;
+        }
+        const int k = __builtin_ctzll(stop);  // wave-uniform (SGPR)
+        const uint32_t xlo = rdlane((uint32_t)x, k);
+        const uint32_t xhi = rdlane((uint32_t)(x >> 32), k);
+        const uint64_t xk = ((uint64_t)xhi << 32) | xlo;
+        si += 8 * k;
+        if (xk != 0) si += __builtin_ctzll(xk) >> 3;
+        return si;
+    }
+}
+
+// Table read of the speculative gather.  For a table in global memory the load
+// bypasses the CU's vector L1 (sc1, served by L2): the wave's own recent 2-byte
+// stores are written through to L2, but an L1-resident copy of the line is not
+// guaranteed to be refreshed before a later gather hits it.
+template <bool kGlobal>
+__device__ __forceinline__ uint32_t tab_load(const uint16_t *t, uint32_t h) {
+    if (kGlobal) return __hip_atomic_load(t + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return t[h];
+}
+
+template <bool kGlobal, typename TablePtr>
+__device__ __forceinline__ int fast2_block(const uint8_t *__restrict__ s, const int n,
+                                           uint8_t *__restrict__ d, const int dlen,
+                                           TablePtr table, uint32_t *tag, const int lane) {
+    const int bound = (int)compress_bound32((uint32_t)n);
+    const bool not_compressible = dlen < bound;  // block.go:110
+    {  // reset(): block.go:94,107 -- an all-zero table is the cleared-bitmap state
+        typedef uint4 __attribute__((may_alias)) uint4_a;
+        uint4_a *t4 = (uint4_a *)(table);
+        for (int k = lane; k < (1 << 16) * 2 / 16; k += kWave) t4[k] = make_uint4(0, 0, 0, 0);
+        for (int k = lane; k < kTagN; k += kWave) tag[k] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+
+    int si = 0, di = 0, anchor = 0;
+    const int sn = n - kMfLimit;
+    bool failed = false, finished = false, pending = false;
+
+    while (si < sn && !failed && !finished) {
+        // Keep the walk state in SGPRs: every value below is wave-uniform by
+        // construction; readfirstlane makes that visible to the compiler.
+        si = (int)rfl((uint32_t)si);
+        di = (int)rfl((uint32_t)di);
+        anchor = (int)rfl((uint32_t)anchor);
+        // ================= Phase A: lane l <-> position wbase + l =================
+        const int wbase = si - 2;  // lane 0 is the position of a pending put(si-2)
+        const int p = wbase + lane;
+        const bool valid = p >= 0 && p <= sn + 1;
+        uint64_t x = 0;
+        if (valid) x = ld64(s + p);
+        const uint32_t h = hash6(x);
+        uint32_t tv = 0;
+        if (valid) tv = tab_load<kGlobal>(table, h);
+        const uint32_t slot = h & (kTagN - 1);
+        if (valid) atomicMin(&tag[slot], (uint32_t)lane);
+        __asm__ volatile("" ::: "memory");
+        uint32_t tmin = 0xFFFFFFFFu;
+        if (valid) tmin = tag[slot];
+        __asm__ volatile("" ::: "memory");
+        if (valid) tag[slot] = 0xFFFFFFFFu;
+        const bool cflag = valid && tmin < (uint32_t)lane;  // an earlier lane shares my slot
+
+        int ref = (int)tv + (p & ~kWinMask);
+        if (ref >= p) ref -= kWinSize;
+        const int off = p - ref;  // > 0 by construction
+        const bool offok = valid && off < kWinSize && ref >= 0;
+        const bool f0ok = offok && p + 12 <= sn;  // stride 0 at p+4 runs iff p+4+8 <= sn
+        const bool f1ok = offok && p + 20 <= sn;
+        const bool bok = offok && ref >= 8;
+        uint32_t cw = 0;
+        uint64_t r0 = 0, q0 = 0, r1 = 0, q1 = 0, rb = 0, qb = 0;
+        if (offok) cw = ld32(s + ref);
+        if (f0ok) {
+            r0 = ld64(s + ref + 4);
+            q0 = ld64(s + p + 4);
+        }
+        if (f1ok) {
+            r1 = ld64(s + ref + 12);
+            q1 = ld64(s + p + 12);
+        }
+        if (bok) {
+            rb = ld64(s + ref - 8);
+            qb = ld64(s + p - 8);
+        }
+        const bool m4 = offok && cw == (uint32_t)x;
+        int fend = p + kMinMatch;
+        bool fmore = false;
+        if (m4 && f0ok) {
+            uint64_t xx = r0 ^ q0;
+            if (xx) {
+                fend += __builtin_ctzll(xx) >> 3;
+            } else {
+                fend += 8;
+                if (f1ok) {
+                    xx = r1 ^ q1;
+                    if (xx) {
+                        fend += __builtin_ctzll(xx) >> 3;
+                    } else {
+                        fend += 8;
+                        fmore = true;  // still equal after 16 bytes: continue cooperatively
+                    }
+                }
+            }
+        }
+        int bwd = 0;
+        bool bmore = false;
+        if (m4) {
+            if (bok) {
+                const uint64_t xx = rb ^ qb;
+                if (xx) {
+                    bwd = __builtin_clzll(xx) >> 3;
+                } else {
+                    bwd = 8;
+                    bmore = true;
+                }
+            } else {
+                bmore = true;  // too close to the block start for the 8-byte loads
+            }
+        }
+        const uint64_t M = ballot(m4), CM = ballot(cflag), FM = ballot(fmore), BM = ballot(bmore);
+        const uint16_t pos16 = (uint16_t)p;
+        uint64_t P = 0;  // window lanes put() since the snapshot
+        if (pending) {   // put(si-2) of the previous match: block.go:254-255
+            if (lane == 0) table[h] = pos16;
+            P = 1;
+            pending = false;
+        }
+
+        // ================= Phase B: the reference's steps over this window =================
+        for (;;) {
+            si = (int)rfl((uint32_t)si);
+            di = (int)rfl((uint32_t)di);
+            anchor = (int)rfl((uint32_t)anchor);
+            P = ((uint64_t)rfl((uint32_t)(P >> 32)) << 32) | rfl((uint32_t)P);
+            const int a = si - wbase;
+            if (a > 61 || si >= sn) break;
+            int j = -1, offset = 0;
+            bool dep = false;
+            // --- probe 0 (get before the puts of this step: block.go:134) ---
+            bool hit0 = (M >> a) & 1, dep0 = false;
+            int off0 = 0;
+            if ((CM >> a) & 1) {
+                const uint64_t E = ballot(h == rdlane(h, a)) & P;
+                if (E) {
+                    const int l = 63 - __builtin_clzll(E);
+                    dep0 = true;
+                    off0 = a - l;
+                    hit0 = rdlane((uint32_t)x, a) == rdlane((uint32_t)x, l);
+                }
+            }
+            // --- probe 1 (also before the puts: block.go:135) ---
+            bool hit1 = (M >> (a + 1)) & 1, dep1 = false;
+            int off1 = 0;
+            if ((CM >> (a + 1)) & 1) {
+                const uint64_t E = ballot(h == rdlane(h, a + 1)) & P;
+                if (E) {
+                    const int l = 63 - __builtin_clzll(E);
+                    dep1 = true;
+                    off1 = a + 1 - l;
+                    hit1 = rdlane((uint32_t)x, a + 1) == rdlane((uint32_t)x, l);
+                }
+            }
+            // --- put(h, si); put(h2, si+1): block.go:136-137 (in this order) ---
+            if ((CM >> (a + 1)) & 1) {
+                // Possibly the same slot: keep the two stores as two instructions in
+                // this order (to the compiler they belong to different threads and
+                // could be merged; the later position must win the slot).
+                if (lane == a) table[h] = pos16;
+                __asm__ volatile("" ::: "memory");
+                if (lane == a + 1) table[h] = pos16;
+                __asm__ volatile("" ::: "memory");
+            } else {
+                if ((unsigned)(lane - a) < 2u) table[h] = pos16;
+            }
+            P |= 3ull << a;
+            if (hit0) {
+                j = 0;
+                dep = dep0;
+                offset = off0;
+            } else {
+                // --- probe 2 sees both puts: block.go:144-145 ---
+                bool hit2 = (M >> (a + 2)) & 1, dep2 = false;
+                int off2 = 0;
+                if ((CM >> (a + 2)) & 1) {
+                    const uint64_t E = ballot(h == rdlane(h, a + 2)) & P;
+                    if (E) {
+                        const int l = 63 - __builtin_clzll(E);
+                        dep2 = true;
+                        off2 = a + 2 - l;
+                        hit2 = rdlane((uint32_t)x, a + 2) == rdlane((uint32_t)x, l);
+                    }
+                }
+                if (hit1) {
+                    j = 1;
+                    dep = dep1;
+                    offset = off1;
+                } else {
+                    __asm__ volatile("" ::: "memory");
+                    if (lane == a + 2) table[h] = pos16;  // block.go:155
+                    __asm__ volatile("" ::: "memory");
+                    P |= 4ull << a;
+                    if (hit2) {
+                        j = 2;
+                        dep = dep2;
+                        offset = off2;
+                    } else {
+                        si += 4 + ((si + 2 - anchor) >> kAdaptSkipLog);  // block.go:159
+                        continue;
+                    }
+                }
+            }
+
+            // ---------------- match found at lane f ----------------
+            const int f = a + j;
+            const int found = si + j;
+            if (!dep) offset = (int)rdlane((uint32_t)off, f);
+            const int mref = found - offset;
+            const int l0 = found - anchor;
+            int back;
+            {
+                const int maxb = l0 < mref ? l0 : mref;  // lLen > 0 && tOff >= 0
+                if (dep) {
+                    back = ext_backward(s, found, mref, 0, maxb, lane);
+                } else {
+                    const int bw = (int)rdlane((uint32_t)bwd, f);
+                    if (((BM >> f) & 1) && maxb > bw)
+                        back = ext_backward(s, found, mref, bw, maxb, lane);
+                    else
+                        back = bw < maxb ? bw : maxb;
+                }
+            }
+            const int m_start = found - back;
+            const int l_len = m_start - anchor;
+            if (dep) {
+                si = ext_forward(s, found + kMinMatch, offset, sn, lane);
+            } else {
+                si = (int)rdlane((uint32_t)fend, f);
+                if ((FM >> f) & 1) si = ext_forward(s, si, offset, sn, lane);
+            }
+            int m_len = si - (m_start + kMinMatch);
+
+            // ---------------- emit: block.go:195-248 ----------------
+            if (di >= dlen) {
+                failed = true;
+                break;
+            }
+            if (lane == 0)
+                d[di] = (uint8_t)((m_len < 0xF ? m_len : 0xF) | ((l_len < 0xF ? l_len : 0xF) << 4));
+            di++;
+            if (l_len >= 0xF) {
+                di = emit_len_tail(d, di, dlen, l_len - 0xF, lane);
+                if (di < 0) {
+                    failed = true;
+                    break;
+                }
+            }
+            if (di + l_len > dlen) {
+                failed = true;
+                break;
+            }
+            {  // literals [anchor, m_start): from the window registers where possible
+                int from_mem = wbase - anchor;  // literals that precede the window
+                if (from_mem > 0) {
+                    if (from_mem > l_len) from_mem = l_len;
+                    wave_copy(d + di, s + anchor, from_mem, lane);
+                } else {
+                    from_mem = 0;
+                }
+                const int la = anchor + from_mem - wbase;  // first literal lane
+                const int lm = m_start - wbase;
+                if (lane >= la && lane < lm) d[di + from_mem + (lane - la)] = (uint8_t)x;
+            }
+            di += l_len + 2;
+            anchor = si;
+            if (di > dlen) {
+                failed = true;
+                break;
+            }
+            if (lane == 0) {
+                d[di - 2] = (uint8_t)offset;
+                d[di - 1] = (uint8_t)(offset >> 8);
+            }
+            if (m_len >= 0xF) {
+                di = emit_len_tail(d, di, dlen, m_len - 0xF, lane);
+                if (di < 0) {
+                    failed = true;
+                    break;
+                }
+            }
+            if (si >= sn) {  // block.go:250-252
+                finished = true;
+                break;
+            }
+            // put(hash(si-2), si-2): block.go:254-255
+            const int q = si - 2 - wbase;
+            if (q <= 63) {
+                __asm__ volatile("" ::: "memory");
+                if (lane == q) table[h] = pos16;
+                __asm__ volatile("" ::: "memory");
+                P |= 1ull << q;
+            } else {
+                pending = true;  // lane 0 of the next window
+            }
+        }
+    }
+
+    // ---------------- last literals: block.go:258-294 ----------------
+    int ret;
+    if (failed) {
+        ret = -1;
+    } else if (not_compressible && anchor == 0) {
+        ret = 0;
+    } else if (di >= dlen) {
+        ret = -1;
+    } else {
+        const int l_len = n - anchor;
+        if (lane == 0) d[di] = (uint8_t)((l_len < 0xF ? l_len : 0xF) << 4);
+        di++;
+        if (l_len >= 0xF) di = emit_len_tail(d, di, dlen, l_len - 0xF, lane);
+        if (di < 0) {
+            ret = -1;
+        } else if (not_compressible && di >= anchor) {
+            ret = 0;
+        } else if (di + l_len > dlen) {
+            ret = -1;
+        } else {
+            wave_copy(d + di, s + anchor, l_len, lane);
+            ret = di + l_len;
+        }
+    }
+    return ret;
+}
+
+__device__ __forceinline__ int block_dlen2(int dst_mode, int n, uint32_t dst_len_x) {
+    return dst_mode == LZ4HIP_DST_FRAME  ? n
+           : dst_mode == LZ4HIP_DST_BOUND ? (int)compress_bound32((uint32_t)n)
+                                          : (int)dst_len_x;
+}
+
+// Table in LDS: one wave (= one workgroup) per block, one block per CU.
+__global__ __launch_bounds__(64) void k_fast2_lds(const uint8_t *__restrict__ src, size_t n_total,
+                                                  uint32_t block_size, int dst_mode,
+                                                  uint32_t dst_len_x, uint8_t *__restrict__ dst,
+                                                  size_t dst_stride,
+                                                  int32_t *__restrict__ result) {
+    __shared__ uint16_t table[1 << 16];
+    __shared__ uint32_t tag[kTagN];
+    const int lane = lane_id();
+    const size_t b = blockIdx.x;
+    const size_t start = b * (size_t)block_size;
+    const size_t left = n_total > start ? n_total - start : 0;
+    const int n = (int)(left < block_size ? left : block_size);
+    const int r = fast2_block<false>(src + start, n, dst + b * dst_stride,
+                                     block_dlen2(dst_mode, n, dst_len_x), table, tag, lane);
+    if (lane == 0) result[b] = r;
+}
+
+// Table in a global-memory slot per resident wave; many waves per CU.
+__global__ __launch_bounds__(64) void k_fast2_gtab(const uint8_t *__restrict__ src, size_t n_total,
+                                                   uint32_t block_size, size_t nb, int dst_mode,
+                                                   uint32_t dst_len_x, uint8_t *__restrict__ dst,
+                                                   size_t dst_stride,
+                                                   int32_t *__restrict__ result,
+                                                   uint16_t *__restrict__ ws) {
+    __shared__ uint32_t tag[kTagN];
+    const int lane = lane_id();
+    uint16_t *table = ws + (size_t)blockIdx.x * (1 << 16);
+    for (size_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const size_t start = b * (size_t)block_size;
+        const size_t left = n_total > start ? n_total - start : 0;
+        const int n = (int)(left < block_size ? left : block_size);
+        const int r = fast2_block<true>(src + start, n, dst + b * dst_stride,
+                                        block_dlen2(dst_mode, n, dst_len_x), table, tag, lane);
+        if (lane == 0) result[b] = r;
+        __syncthreads();
+    }
+}
+
+hipError_t launch_fast2(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
+                        uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,
+                        uint16_t *ws, size_t slots, hipStream_t st) {
+    if (nb == 0) return hipSuccess;
+    if (ws && slots) {
+        const size_t grid = nb < slots ? nb : slots;
+        hipLaunchKernelGGL(k_fast2_gtab, dim3((unsigned)grid), dim3(kWave), 0, st, src, n, bs, nb,
+                           dst_mode, dst_len_x, dst, dst_stride, result, ws);
+    } else {
+        hipLaunchKernelGGL(k_fast2_lds, dim3((unsigned)nb), dim3(kWave), 0, st, src, n, bs,
+                           dst_mode, dst_len_x, dst, dst_stride, result);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace lz4hip

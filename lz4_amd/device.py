@@ -41,9 +41,10 @@ def compress_blocks(src, block_size, level=0, dst_mode=_lib.DST_FRAME, out=None,
     if result is None:
         result = torch.zeros(max(nb, 1), dtype=torch.int32, device=src.device)
     if level == 0:
+        ws_ptr, ws_len = (workspace.data_ptr(), workspace.numel()) if workspace is not None else (None, 0)
         _lib.check(lib.lz4hip_compress_fast_blocks(src.data_ptr(), n, block_size, dst_mode,
                                                    out.data_ptr(), stride, result.data_ptr(),
-                                                   _stream_ptr()))
+                                                   ws_ptr, ws_len, _stream_ptr()))
     else:
         need = lib.lz4hip_hc_workspace_bytes(nb)
         if workspace is None or workspace.numel() < need:

@@ -65,10 +65,10 @@ def test_argument_validation_without_gpu():
     """Shape checks happen on the host before any launch."""
     from lz4_amd import _lib
     lib = _lib.load()
-    assert lib.lz4hip_compress_fast_blocks(16, 100, 12345, 0, 16, 65536, 16, None) == _lib.ERR_ARG
+    assert lib.lz4hip_compress_fast_blocks(16, 100, 12345, 0, 16, 65536, 16, None, 0, None) == _lib.ERR_ARG
     assert b"block size" in lib.lz4hip_last_error()
-    assert lib.lz4hip_compress_fast_blocks(17, 100, 1 << 16, 0, 16, 65536, 16, None) == _lib.ERR_ARG
-    assert lib.lz4hip_compress_fast_blocks(16, 100, 1 << 16, 0, 16, 1024, 16, None) == _lib.ERR_ARG
+    assert lib.lz4hip_compress_fast_blocks(17, 100, 1 << 16, 0, 16, 65536, 16, None, 0, None) == _lib.ERR_ARG
+    assert lib.lz4hip_compress_fast_blocks(16, 100, 1 << 16, 0, 16, 1024, 16, None, 0, None) == _lib.ERR_ARG
     assert lib.lz4hip_uncompress_blocks(None, None, None, 4, None, 0, 0, None, None) == _lib.ERR_ARG
     assert lib.lz4hip_hc_workspace_bytes(1) == 2 * 65536 * 4
 
