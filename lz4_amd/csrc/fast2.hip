@@ -177,14 +177,18 @@ __device__ __forceinline__ int fast2_block(const uint8_t *__restrict__ s, const 
                 bmore = true;  // too close to the block start for the 8-byte loads
             }
         }
-        const uint64_t M = ballot(m4), CM = ballot(cflag), FM = ballot(fmore), BM = ballot(bmore);
+        // Per-lane answers packed for one readlane at match time:
+        // offset[15:0] | bwd[19:16] | (fend - p)[24:20] | fmore[25] | bmore[26]
+        const uint32_t pk = (uint32_t)off | ((uint32_t)bwd << 16) | ((uint32_t)(fend - p) << 20) |
+                            ((uint32_t)fmore << 25) | ((uint32_t)bmore << 26);
+        const uint64_t M = ballot(m4), CM = ballot(cflag);
+        const uint64_t ATT = M | CM;  // lanes that need a look during the walk
         const uint16_t pos16 = (uint16_t)p;
-        uint64_t P = 0;  // window lanes put() since the snapshot
-        if (pending) {   // put(si-2) of the previous match: block.go:254-255
-            if (lane == 0) table[h] = pos16;
-            P = 1;
-            pending = false;
-        }
+        // Window lanes put() since the snapshot.  The table itself is written once,
+        // when the window closes: until then every dependency on these puts is
+        // resolved in registers (cflag + exact ballot below).
+        uint64_t P = pending ? 1ull : 0ull;  // lane 0 = put(si-2) of the previous match (:254-255)
+        pending = false;
 
         // ================= Phase B: the reference's steps over this window =================
         for (;;) {
@@ -194,173 +198,186 @@ __device__ __forceinline__ int fast2_block(const uint8_t *__restrict__ s, const 
             P = ((uint64_t)rfl((uint32_t)(P >> 32)) << 32) | rfl((uint32_t)P);
             const int a = si - wbase;
             if (a > 61 || si >= sn) break;
-            int j = -1, offset = 0;
-            bool dep = false;
-            // --- probe 0 (get before the puts of this step: block.go:134) ---
-            bool hit0 = (M >> a) & 1, dep0 = false;
-            int off0 = 0;
-            if ((CM >> a) & 1) {
-                const uint64_t E = ballot(h == rdlane(h, a)) & P;
-                if (E) {
-                    const int l = 63 - __builtin_clzll(E);
-                    dep0 = true;
-                    off0 = a - l;
-                    hit0 = rdlane((uint32_t)x, a) == rdlane((uint32_t)x, l);
-                }
-            }
-            // --- probe 1 (also before the puts: block.go:135) ---
-            bool hit1 = (M >> (a + 1)) & 1, dep1 = false;
-            int off1 = 0;
-            if ((CM >> (a + 1)) & 1) {
-                const uint64_t E = ballot(h == rdlane(h, a + 1)) & P;
-                if (E) {
-                    const int l = 63 - __builtin_clzll(E);
-                    dep1 = true;
-                    off1 = a + 1 - l;
-                    hit1 = rdlane((uint32_t)x, a + 1) == rdlane((uint32_t)x, l);
-                }
-            }
-            // --- put(h, si); put(h2, si+1): block.go:136-137 (in this order) ---
-            if ((CM >> (a + 1)) & 1) {
-                // Possibly the same slot: keep the two stores as two instructions in
-                // this order (to the compiler they belong to different threads and
-                // could be merged; the later position must win the slot).
-                if (lane == a) table[h] = pos16;
-                __asm__ volatile("" ::: "memory");
-                if (lane == a + 1) table[h] = pos16;
-                __asm__ volatile("" ::: "memory");
-            } else {
-                if ((unsigned)(lane - a) < 2u) table[h] = pos16;
-            }
-            P |= 3ull << a;
-            if (hit0) {
-                j = 0;
-                dep = dep0;
-                offset = off0;
-            } else {
-                // --- probe 2 sees both puts: block.go:144-145 ---
-                bool hit2 = (M >> (a + 2)) & 1, dep2 = false;
-                int off2 = 0;
-                if ((CM >> (a + 2)) & 1) {
-                    const uint64_t E = ballot(h == rdlane(h, a + 2)) & P;
-                    if (E) {
-                        const int l = 63 - __builtin_clzll(E);
-                        dep2 = true;
-                        off2 = a + 2 - l;
-                        hit2 = rdlane((uint32_t)x, a + 2) == rdlane((uint32_t)x, l);
-                    }
-                }
-                if (hit1) {
-                    j = 1;
-                    dep = dep1;
-                    offset = off1;
+            const uint32_t att3 = (uint32_t)(ATT >> a) & 7u;
+            if (att3 == 0) {
+                // No candidate verifies at si, si+1, si+2 and no put can interfere:
+                // the three puts happen (:136-137,155) and the step skips (:159).
+                const int d0 = si + 2 - anchor;
+                if (d0 <= 64 && si + 64 < sn) {
+                    // The skip stays 4 bytes for every step that starts in this window:
+                    // take all the clean steps up to the next lane that needs a look.
+                    const uint64_t pat = 0x7777777777777777ull << a;  // probed lanes a+4k+{0,1,2}
+                    const uint64_t hot = ATT & pat;
+                    const int kmax = ((61 - a) >> 2) + 1;  // steps that start at a lane <= 61
+                    // clean steps before the one holding the next hot lane (>= 1: att3 == 0)
+                    int k = hot ? (__builtin_ctzll(hot) - a) >> 2 : kmax;
+                    if (k > kmax) k = kmax;
+                    const int e = a + 4 * k;  // first lane not covered (<= 65)
+                    P |= e >= 64 ? pat : (pat & ((1ull << e) - 1));
+                    si += 4 * k;
                 } else {
-                    __asm__ volatile("" ::: "memory");
-                    if (lane == a + 2) table[h] = pos16;  // block.go:155
-                    __asm__ volatile("" ::: "memory");
-                    P |= 4ull << a;
-                    if (hit2) {
-                        j = 2;
-                        dep = dep2;
-                        offset = off2;
-                    } else {
-                        si += 4 + ((si + 2 - anchor) >> kAdaptSkipLog);  // block.go:159
-                        continue;
+                    P |= 7ull << a;
+                    si += 4 + (d0 >> kAdaptSkipLog);
+                }
+                continue;
+            }
+            int j, offset = 0;
+            bool dep = false;
+            const uint32_t c3 = (uint32_t)(CM >> a) & 7u;
+            if (c3 == 0) {
+                // Snapshot answers are exact for all three probes.
+                j = __builtin_ctz(att3);
+                P |= (j == 2 ? 7ull : 3ull) << a;
+            } else {
+                // Some probe lane shares its tag slot with an earlier lane: resolve the
+                // probes in the reference's order against the puts made so far.
+                bool hit[3], dp[3];
+                int of[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int b = a + t;
+                    // probes 0 and 1 see the puts before this step; probe 2 also sees
+                    // put(si), put(si+1)  (block.go:134-137,145)
+                    const uint64_t vis = t == 2 ? (P | (3ull << a)) : P;
+                    hit[t] = (M >> b) & 1;
+                    dp[t] = false;
+                    of[t] = 0;
+                    if ((CM >> b) & 1) {
+                        const uint64_t E = ballot(h == rdlane(h, b)) & vis;
+                        if (E) {
+                            const int l = 63 - __builtin_clzll(E);  // the latest such put
+                            dp[t] = true;
+                            of[t] = b - l;
+                            hit[t] = rdlane((uint32_t)x, b) == rdlane((uint32_t)x, l);
+                        }
                     }
                 }
+                if (hit[0]) {
+                    j = 0;
+                } else if (hit[1]) {
+                    j = 1;
+                } else if (hit[2]) {
+                    j = 2;
+                } else {
+                    P |= 7ull << a;
+                    si += 4 + ((si + 2 - anchor) >> kAdaptSkipLog);
+                    continue;
+                }
+                dep = dp[j];
+                offset = of[j];
+                P |= (j == 2 ? 7ull : 3ull) << a;
             }
 
             // ---------------- match found at lane f ----------------
             const int f = a + j;
             const int found = si + j;
-            if (!dep) offset = (int)rdlane((uint32_t)off, f);
+            const uint32_t pkf = rdlane(pk, f);
+            if (!dep) offset = (int)(pkf & 0xFFFFu);
             const int mref = found - offset;
             const int l0 = found - anchor;
+            const int maxb = l0 < mref ? l0 : mref;  // lLen > 0 && tOff >= 0
             int back;
-            {
-                const int maxb = l0 < mref ? l0 : mref;  // lLen > 0 && tOff >= 0
-                if (dep) {
-                    back = ext_backward(s, found, mref, 0, maxb, lane);
-                } else {
-                    const int bw = (int)rdlane((uint32_t)bwd, f);
-                    if (((BM >> f) & 1) && maxb > bw)
-                        back = ext_backward(s, found, mref, bw, maxb, lane);
-                    else
-                        back = bw < maxb ? bw : maxb;
-                }
+            if (dep) {
+                back = ext_backward(s, found, mref, 0, maxb, lane);
+                si = ext_forward(s, found + kMinMatch, offset, sn, lane);
+            } else {
+                const int bw = (int)((pkf >> 16) & 0xFu);
+                back = bw < maxb ? bw : maxb;
+                if (((pkf >> 26) & 1u) && maxb > bw) back = ext_backward(s, found, mref, bw, maxb, lane);
+                si = found + (int)((pkf >> 20) & 0x1Fu);
+                if ((pkf >> 25) & 1u) si = ext_forward(s, si, offset, sn, lane);
             }
             const int m_start = found - back;
             const int l_len = m_start - anchor;
-            if (dep) {
-                si = ext_forward(s, found + kMinMatch, offset, sn, lane);
-            } else {
-                si = (int)rdlane((uint32_t)fend, f);
-                if ((FM >> f) & 1) si = ext_forward(s, si, offset, sn, lane);
-            }
             int m_len = si - (m_start + kMinMatch);
 
             // ---------------- emit: block.go:195-248 ----------------
-            if (di >= dlen) {
-                failed = true;
-                break;
-            }
-            if (lane == 0)
-                d[di] = (uint8_t)((m_len < 0xF ? m_len : 0xF) | ((l_len < 0xF ? l_len : 0xF) << 4));
-            di++;
-            if (l_len >= 0xF) {
-                di = emit_len_tail(d, di, dlen, l_len - 0xF, lane);
-                if (di < 0) {
+            const int la = anchor - wbase;  // first literal lane (may be negative)
+            if (l_len < 0xF && m_len < 0xF && la >= 0 && di + l_len + 3 <= dlen) {
+                // common case, one token byte and no length runs; every check of
+                // :196-245 holds because di + 1 + l_len + 2 <= dlen.
+                if (lane == 0) d[di] = (uint8_t)(m_len | (l_len << 4));
+                if ((unsigned)(lane - la) < (unsigned)l_len) d[di + 1 + (lane - la)] = (uint8_t)x;
+                di += 1 + l_len + 2;
+                if (lane == 0) {
+                    d[di - 2] = (uint8_t)offset;
+                    d[di - 1] = (uint8_t)(offset >> 8);
+                }
+            } else {
+                if (di >= dlen) {
                     failed = true;
                     break;
                 }
-            }
-            if (di + l_len > dlen) {
-                failed = true;
-                break;
-            }
-            {  // literals [anchor, m_start): from the window registers where possible
-                int from_mem = wbase - anchor;  // literals that precede the window
-                if (from_mem > 0) {
-                    if (from_mem > l_len) from_mem = l_len;
-                    wave_copy(d + di, s + anchor, from_mem, lane);
-                } else {
-                    from_mem = 0;
+                if (lane == 0)
+                    d[di] = (uint8_t)((m_len < 0xF ? m_len : 0xF) | ((l_len < 0xF ? l_len : 0xF) << 4));
+                di++;
+                if (l_len >= 0xF) {
+                    di = emit_len_tail(d, di, dlen, l_len - 0xF, lane);
+                    if (di < 0) {
+                        failed = true;
+                        break;
+                    }
                 }
-                const int la = anchor + from_mem - wbase;  // first literal lane
-                const int lm = m_start - wbase;
-                if (lane >= la && lane < lm) d[di + from_mem + (lane - la)] = (uint8_t)x;
+                if (di + l_len > dlen) {
+                    failed = true;
+                    break;
+                }
+                {  // literals [anchor, m_start): from the window registers where possible
+                    int from_mem = -la;  // literals that precede the window
+                    if (from_mem > 0) {
+                        if (from_mem > l_len) from_mem = l_len;
+                        wave_copy(d + di, s + anchor, from_mem, lane);
+                    } else {
+                        from_mem = 0;
+                    }
+                    const int lb = la + from_mem;  // first literal lane held in registers
+                    const int lm = m_start - wbase;
+                    if (lane >= lb && lane < lm) d[di + from_mem + (lane - lb)] = (uint8_t)x;
+                }
+                di += l_len + 2;
+                if (di > dlen) {
+                    failed = true;
+                    break;
+                }
+                if (lane == 0) {
+                    d[di - 2] = (uint8_t)offset;
+                    d[di - 1] = (uint8_t)(offset >> 8);
+                }
+                if (m_len >= 0xF) {
+                    di = emit_len_tail(d, di, dlen, m_len - 0xF, lane);
+                    if (di < 0) {
+                        failed = true;
+                        break;
+                    }
+                }
             }
-            di += l_len + 2;
             anchor = si;
-            if (di > dlen) {
-                failed = true;
-                break;
-            }
-            if (lane == 0) {
-                d[di - 2] = (uint8_t)offset;
-                d[di - 1] = (uint8_t)(offset >> 8);
-            }
-            if (m_len >= 0xF) {
-                di = emit_len_tail(d, di, dlen, m_len - 0xF, lane);
-                if (di < 0) {
-                    failed = true;
-                    break;
-                }
-            }
             if (si >= sn) {  // block.go:250-252
                 finished = true;
                 break;
             }
             // put(hash(si-2), si-2): block.go:254-255
             const int q = si - 2 - wbase;
-            if (q <= 63) {
-                __asm__ volatile("" ::: "memory");
-                if (lane == q) table[h] = pos16;
-                __asm__ volatile("" ::: "memory");
+            if (q <= 63)
                 P |= 1ull << q;
-            } else {
+            else
                 pending = true;  // lane 0 of the next window
+        }
+
+        // ---- close the window: write this window's puts to the table ----
+        if (!failed && !finished) {
+            // Lanes whose tag slot no earlier lane shares hit distinct slots: one store.
+            if ((P & ~CM) >> lane & 1) table[h] = pos16;
+            // The others may share a slot with an earlier put: store them after, one
+            // at a time in position order, so the latest put owns the slot.
+            uint64_t Pd = P & CM;
+            while (Pd) {
+                __asm__ volatile("" ::: "memory");
+                const int l = __builtin_ctzll(Pd);
+                Pd &= Pd - 1;
+                if (lane == l) table[h] = pos16;
             }
+            __asm__ volatile("" ::: "memory");
         }
     }
 
