@@ -48,6 +48,7 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 constexpr size_t kFastSlots = 8192;             // resident waves of the global-table Fast kernel
 constexpr size_t kFastSlotBytes = 65536 * 2;    // one u16 table
+constexpr size_t kFastGlobalMinBlocks = 1024;   // below this the LDS-table kernel is used
 constexpr size_t kHcSlots = 2048;               // resident workgroups of the HC kernel
 constexpr size_t kHcSlotBytes = 2 * 65536 * 4;  // hashTable + chainTable
 constexpr size_t kMaxSingleBlock = 1u << 30;    // int32 positions inside a block
@@ -114,7 +115,9 @@ int lz4hip_device_count(void) {
 size_t lz4hip_compress_bound(size_t n) { return n + n / 255 + 16; }
 
 size_t lz4hip_fast_workspace_bytes(size_t n_blocks) {
-    return (n_blocks < kFastSlots ? (n_blocks ? n_blocks : 1) : kFastSlots) * kFastSlotBytes;
+    if (n_blocks < kFastGlobalMinBlocks) return 0;  // LDS-table kernel, no workspace needed
+    const size_t want = 4096;  // 16 waves per CU on 256 CUs
+    return (n_blocks < want ? n_blocks : want) * kFastSlotBytes;
 }
 
 int lz4hip_compress_fast_blocks(const void *d_src, size_t n, uint32_t block_size, int dst_mode,
@@ -135,6 +138,9 @@ int lz4hip_compress_fast_blocks(const void *d_src, size_t n, uint32_t block_size
     if (slots > kFastSlots) slots = kFastSlots;
     if (d_workspace && (!aligned16(d_workspace) || slots == 0))
         return fail(LZ4HIP_ERR_ARG, "workspace unaligned or smaller than one table");
+    // Few blocks: one block per CU with the table in LDS finishes each block sooner.
+    // Many blocks: global tables and many waves per CU give the higher throughput.
+    if (nb < kFastGlobalMinBlocks) slots = 0;
     HIPCHK(launch_fast_any((const uint8_t *)d_src, n, block_size, nb, dst_mode, 0, (uint8_t *)d_dst,
                        dst_stride, d_result, (uint16_t *)d_workspace, slots,
                        (hipStream_t)stream));
@@ -395,7 +401,7 @@ int64_t lz4hip_frame_compress(const uint8_t *src, size_t n, uint32_t block_size,
     uint8_t hdr[16], trl[8];
     const size_t hlen = lz4hip_frame_header(hdr, block_size, flags, content_size);
 
-    DevBuf d_src, d_comp, d_res, d_xxh, d_off, d_frame, d_cs;
+    DevBuf d_src, d_comp, d_res, d_xxh, d_off, d_frame, d_cs, d_fws;
     hipStream_t s_main = nullptr, s_sum = nullptr;
     HIPCHK(d_src.alloc(n + 16));
     HIPCHK(d_comp.alloc(nb_data * (size_t)block_size));
@@ -423,9 +429,11 @@ int64_t lz4hip_frame_compress(const uint8_t *src, size_t n, uint32_t block_size,
         if (csum) STEP(launch_xxh32_stream(d_src.as<uint8_t>(), n, d_cs.as<uint32_t>(), s_sum));
         if (nb_data) {
             if (level == 0) {
+                const size_t wsb = lz4hip_fast_workspace_bytes(nb_data);
+                if (wsb) STEP(d_fws.alloc(wsb));
                 STEP(launch_fast_any(d_src.as<uint8_t>(), n, block_size, nb_data, LZ4HIP_DST_FRAME, 0,
-                                 d_comp.as<uint8_t>(), block_size, d_res.as<int32_t>(), nullptr, 0,
-                                 s_main));
+                                 d_comp.as<uint8_t>(), block_size, d_res.as<int32_t>(),
+                                 d_fws.as<uint16_t>(), wsb / kFastSlotBytes, s_main));
             } else {
                 DevBuf d_ws;
                 const size_t slots = nb_data < kHcSlots ? nb_data : kHcSlots;

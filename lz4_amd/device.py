@@ -23,6 +23,23 @@ def n_blocks(n, block_size):
     return (n + block_size - 1) // block_size
 
 
+_ws_cache = {}
+
+
+def fast_workspace(nb, device):
+    """Cached hash-table workspace of the Fast compressor for `device` (None when the
+    batch is small enough for the LDS-table kernel)."""
+    need = _lib.load().lz4hip_fast_workspace_bytes(nb)
+    if need == 0:
+        return None
+    key = (device.type, device.index)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
 def compress_blocks(src, block_size, level=0, dst_mode=_lib.DST_FRAME, out=None, result=None,
                     workspace=None):
     """Compress every block_size piece of `src` (1-D CUDA uint8, 16-byte aligned).
@@ -41,6 +58,8 @@ def compress_blocks(src, block_size, level=0, dst_mode=_lib.DST_FRAME, out=None,
     if result is None:
         result = torch.zeros(max(nb, 1), dtype=torch.int32, device=src.device)
     if level == 0:
+        if workspace is None:
+            workspace = fast_workspace(nb, src.device)
         ws_ptr, ws_len = (workspace.data_ptr(), workspace.numel()) if workspace is not None else (None, 0)
         _lib.check(lib.lz4hip_compress_fast_blocks(src.data_ptr(), n, block_size, dst_mode,
                                                    out.data_ptr(), stride, result.data_ptr(),

@@ -188,3 +188,16 @@ def test_xxh32_stream_update_chain(T, oracle):
         d = dev.xxh32_stream_update(piece, piece.numel(), state, i == 0, i == 2)
     assert (int(d.item()) & 0xFFFFFFFF) == oracle.ChecksumZero(data)
     assert (int(dev.xxh32_stream(src).item()) & 0xFFFFFFFF) == oracle.ChecksumZero(data)
+
+
+def test_fast_many_blocks_global_table_kernel(T, oracle):
+    """>= 1024 blocks selects the global-table kernel (many waves per CU); its bytes
+    must equal the LDS-table kernel's and the oracle's."""
+    from lz4_amd import corpus, device as dev
+    bs = 1 << 16
+    data = corpus.generate("mixed", 123, 1500 * bs + 999)
+    assert dev.fast_workspace(1501, T.device("cuda", 0)) is not None
+    _check_blocks(T, oracle, data, bs)
+    bs = 1 << 18
+    data = corpus.generate("text", 7 << 20, 1100 * bs)
+    _check_blocks(T, oracle, data, bs)
