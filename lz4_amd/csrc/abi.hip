@@ -89,6 +89,18 @@ hipError_t launch_fast_any(const uint8_t *src, size_t n, uint32_t bs, size_t nb,
                : launch_fast2(src, n, bs, nb, dst_mode, dst_len_x, dst, dst_stride, result, ws, slots, st);
 }
 
+// Decoder generation: 2 = window-parallel two-pass (decode2.hip, default), 1 = serial walk.
+hipError_t launch_decode_any(const uint8_t *src, const uint64_t *off, const uint32_t *sw, size_t nb,
+                             uint8_t *dst, size_t dst_stride, uint32_t dst_len, uint32_t prefix,
+                             int32_t *out_len, hipStream_t st) {
+    static const int g = [] {
+        const char *e = getenv("LZ4HIP_DECODE");
+        return (e && e[0] == '1') ? 1 : 2;
+    }();
+    return g == 1 ? launch_decode(src, off, sw, nb, dst, dst_stride, dst_len, prefix, out_len, st)
+                  : launch_decode2(src, off, sw, nb, dst, dst_stride, dst_len, prefix, out_len, st);
+}
+
 // RAII device buffer for the host-pointer entry points.
 struct DevBuf {
     void *p = nullptr;
@@ -185,7 +197,7 @@ int lz4hip_uncompress_blocks(const void *d_src, const uint64_t *d_src_off,
     if (dst_stride < dst_len) return fail(LZ4HIP_ERR_ARG, "dst_stride smaller than dst_len");
     if (dst_len > kMaxSingleBlock) return fail(LZ4HIP_ERR_ARG, "dst_len too large");
     if (n_blocks > 0x7fffffffu) return fail(LZ4HIP_ERR_ARG, "too many blocks");
-    HIPCHK(launch_decode((const uint8_t *)d_src, d_src_off, d_size_words, n_blocks,
+    HIPCHK(launch_decode_any((const uint8_t *)d_src, d_src_off, d_size_words, n_blocks,
                          (uint8_t *)d_dst, dst_stride, dst_len, 0, d_out_len,
                          (hipStream_t)stream));
     return LZ4HIP_OK;
@@ -342,7 +354,7 @@ static int64_t uncompress_one(const uint8_t *src, size_t n, uint8_t *dst, size_t
     } meta = {0, (uint32_t)n, 0};
     HIPCHK(hipMemcpy(d_meta.p, &meta, sizeof meta, hipMemcpyHostToDevice));
     uint8_t *m = d_meta.as<uint8_t>();
-    HIPCHK(launch_decode(d_src.as<uint8_t>(), (const uint64_t *)m, (const uint32_t *)(m + 8), 1,
+    HIPCHK(launch_decode_any(d_src.as<uint8_t>(), (const uint64_t *)m, (const uint32_t *)(m + 8), 1,
                          d_out.as<uint8_t>() + dict_len, 0, (uint32_t)dst_len,
                          (uint32_t)dict_len, (int32_t *)(m + 12), nullptr));
     HIPCHK(hipMemcpy(&meta, d_meta.p, sizeof meta, hipMemcpyDeviceToHost));
@@ -563,7 +575,7 @@ int64_t lz4hip_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size
     HIPCHK(hipMemcpy(d_src.p, src, n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_off.p, off.data(), nb * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_sw.p, sw.data(), nb * 4, hipMemcpyHostToDevice));
-    HIPCHK(launch_decode(d_src.as<uint8_t>(), d_off.as<uint64_t>(), d_sw.as<uint32_t>(), nb,
+    HIPCHK(launch_decode_any(d_src.as<uint8_t>(), d_off.as<uint64_t>(), d_sw.as<uint32_t>(), nb,
                          d_out.as<uint8_t>(), bs, bs, 0, d_len.as<int32_t>(), nullptr));
     if (bsum)  // verified on the DECODED bytes: lz4stream/block.go:330-335
         HIPCHK(launch_xxh32_blocks(d_out.as<uint8_t>(), nb * (size_t)bs, bs, nullptr,
