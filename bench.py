@@ -50,12 +50,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     _lib.require_gpu()
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # LZ4_BENCH_ONE_DEVICE=1 rehearses the N>1 path on a single-GPU box: every rank
+    # uses cuda:0 and the (tiny) control collectives run over gloo.
+    one_dev = os.environ.get("LZ4_BENCH_ONE_DEVICE") == "1"
+    dev_index = 0 if one_dev else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if one_dev:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     def barrier():
         torch.cuda.synchronize()
@@ -127,7 +134,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_dev else device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
