@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblz4hip.so")
+# LZ4HIP_LIB overrides the path (kernel experiments); default is the in-tree build.
+LIB_PATH = os.environ.get("LZ4HIP_LIB") or os.path.join(_HERE, "liblz4hip.so")
 
 # status codes of include/lz4hip.h
 OK, ERR_ARG, ERR_HIP, ERR_SHORT, ERR_FRAME = 0, -1, -2, -3, -4

@@ -72,21 +72,24 @@ uint32_t host_xxh32_short(const uint8_t *p, size_t n) {  // n < 16
     return h;
 }
 
-// Kernel generation of the Fast compressor: 2 = window-parallel (fast2.hip, default),
-// 1 = step-serial (fast.hip).  LZ4HIP_FAST=1 selects the older kernel for A/B runs.
+// Kernel generation of the Fast compressor: 3 = window-parallel with vector emission
+// (fast3.hip, default), 2 = window-parallel with scalar emission (fast2.hip),
+// 1 = step-serial (fast.hip).  LZ4HIP_FAST selects an older one for A/B runs.
 int fast_generation() {
     static const int g = [] {
         const char *e = getenv("LZ4HIP_FAST");
-        return (e && e[0] == '1') ? 1 : 2;
+        return (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 3;
     }();
     return g;
 }
 hipError_t launch_fast_any(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
                            uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,
                            uint16_t *ws, size_t slots, hipStream_t st) {
-    return fast_generation() == 1
-               ? launch_fast(src, n, bs, nb, dst_mode, dst_len_x, dst, dst_stride, result, ws, slots, st)
-               : launch_fast2(src, n, bs, nb, dst_mode, dst_len_x, dst, dst_stride, result, ws, slots, st);
+    switch (fast_generation()) {
+    case 1: return launch_fast(src, n, bs, nb, dst_mode, dst_len_x, dst, dst_stride, result, ws, slots, st);
+    case 2: return launch_fast2(src, n, bs, nb, dst_mode, dst_len_x, dst, dst_stride, result, ws, slots, st);
+    default: return launch_fast3(src, n, bs, nb, dst_mode, dst_len_x, dst, dst_stride, result, ws, slots, st);
+    }
 }
 
 // Decoder generation: 2 = window-parallel two-pass (decode2.hip, default), 1 = serial walk.
