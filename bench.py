@@ -220,7 +220,7 @@ def main():
             "decompress_GBps": round(n / t_dec / 1e9, 3),
             "kernel_ms": {"fast_compress": round(t_comp * 1e3, 3), "xxh32_blocks": round(t_xxh * 1e3, 3),
                           "decode": round(t_dec * 1e3, 3)},
-            "roofline": {"bound": "hbm", "kernel": "k_fast2_gtab",
+            "roofline": {"bound": "hbm", "kernel": "k_fast3_gtab",
                          "achieved": round(alg_bytes / t_comp / 1e9, 3), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(alg_bytes / t_comp / 1e9 / HBM_PEAK_GBPS, 5),
                          "traffic": None,

@@ -493,6 +493,83 @@ int64_t lz4hip_frame_compress(const uint8_t *src, size_t n, uint32_t block_size,
     return rc == LZ4HIP_OK ? total : rc;
 }
 
+// Legacy frame (magic 0x184C2102, frame.go:20,46-51,169-174): 8 MiB independent
+// blocks, no checksums, no end mark.  block.Read's legacy rules
+// (lz4stream/block.go:284-294): a size word equal to the magic starts a
+// concatenated frame; a size word equal to the bytes decoded so far ends the
+// stream (the Linux kernel appends the total size).  That last rule needs the
+// decoded sizes, so: index every candidate block on the host, decode them all in
+// one batch, then apply the rule in stream order and drop what follows the end.
+static int64_t legacy_uncompress(const uint8_t *src, size_t n, size_t si, uint8_t *dst,
+                                 size_t dst_cap) {
+    const uint32_t cap = 8u << 20;
+    auto rd32 = [&](size_t at) {
+        uint32_t v;
+        memcpy(&v, src + at, 4);
+        return v;
+    };
+    struct Cand {
+        size_t word_at;
+        uint32_t word;
+    };
+    std::vector<Cand> cand;
+    std::vector<uint64_t> off;
+    std::vector<uint32_t> sw;
+    int stop = 0;  // why the index ended: 0 = end of input, 1 = oversize word, 2 = truncated payload
+    while (n - si >= 4) {
+        const uint32_t x = rd32(si);
+        if (x == 0x184C2102u) {
+            si += 4;
+            continue;
+        }
+        const uint32_t size = x & 0x7FFFFFFFu;
+        if (size > cap) {
+            cand.push_back({si, x});
+            stop = 1;
+            break;
+        }
+        if (n - si - 4 < size) {
+            cand.push_back({si, x});
+            stop = 2;
+            break;
+        }
+        cand.push_back({si, x});
+        off.push_back(si + 4);
+        sw.push_back(x);
+        si += 4 + (size_t)size;
+    }
+    const size_t nb = sw.size();
+    std::vector<int32_t> len(nb);
+    DevBuf d_src, d_off, d_sw, d_out, d_len;
+    if (nb) {
+        HIPCHK(d_src.alloc(n));
+        HIPCHK(d_off.alloc(nb * 8));
+        HIPCHK(d_sw.alloc(nb * 4));
+        HIPCHK(d_out.alloc(nb * (size_t)cap));
+        HIPCHK(d_len.alloc(nb * 4));
+        HIPCHK(hipMemcpy(d_src.p, src, n, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_off.p, off.data(), nb * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_sw.p, sw.data(), nb * 4, hipMemcpyHostToDevice));
+        HIPCHK(launch_decode_any(d_src.as<uint8_t>(), d_off.as<uint64_t>(), d_sw.as<uint32_t>(), nb,
+                                 d_out.as<uint8_t>(), cap, cap, 0, d_len.as<int32_t>(), nullptr));
+        HIPCHK(hipMemcpy(len.data(), d_len.p, nb * 4, hipMemcpyDeviceToHost));
+    }
+    size_t total = 0;
+    for (size_t b = 0; b < cand.size(); b++) {
+        if (cand[b].word == (uint32_t)total) return (int64_t)total;  // :289-293
+        if (b >= nb)  // the word that ended the index is a real block header
+            return stop == 1 ? fail(LZ4HIP_ERR_BLOCK_SIZE, "legacy block larger than 8 MiB")
+                             : fail(LZ4HIP_ERR_FRAME, "truncated frame");
+        if (len[b] < 0) return fail(LZ4HIP_ERR_BLOCK, "invalid source or destination buffer too short");
+        if (total + (size_t)len[b] > dst_cap) return fail(LZ4HIP_ERR_SHORT, "dst_cap too small");
+        if (len[b])
+            HIPCHK(hipMemcpy(dst + total, d_out.as<uint8_t>() + b * (size_t)cap, (size_t)len[b],
+                             hipMemcpyDeviceToHost));
+        total += (size_t)len[b];
+    }
+    return (int64_t)total;
+}
+
 int64_t lz4hip_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_cap) {
     if (!src || (dst_cap && !dst)) return fail(LZ4HIP_ERR_ARG, "null pointer");
     size_t si = 0;
@@ -515,7 +592,8 @@ int64_t lz4hip_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size
             si += skip;
             continue;
         }
-        return fail(LZ4HIP_ERR_FRAME, "invalid frame magic (legacy frames are not handled)");
+        if (magic == 0x184C2102u) return legacy_uncompress(src, n, si, dst, dst_cap);
+        return fail(LZ4HIP_ERR_FRAME, "invalid frame magic");
     }
     if (n - si < 3) return fail(LZ4HIP_ERR_FRAME, "truncated frame");
     const size_t d0 = si;

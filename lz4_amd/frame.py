@@ -162,7 +162,15 @@ def _decoded_bound(s):
     n = s.size
     if n < 7:
         return 0
-    si = 4
+    if int.from_bytes(s[:4].tobytes(), "little") == 0x184C2102:   # legacy: 8 MiB blocks
+        si, nb = 4, 0
+        while si + 4 <= n:
+            w = int.from_bytes(s[si:si + 4].tobytes(), "little")
+            si += 4
+            if w != 0x184C2102:
+                si += w & 0x7FFFFFFF
+                nb += 1
+        return nb << 23
     flg = int(s[4])
     bd = int(s[5])
     si = 6 + (8 if flg >> 3 & 1 else 0) + 1

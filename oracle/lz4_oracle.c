@@ -598,6 +598,38 @@ int64_t lz4o_frame_compress(const uint8_t *src, size_t n, uint32_t block_size, u
     return (int64_t)k;
 }
 
+/* Legacy frame (magic 0x184C2102): frame.go:46-51,169-174; block.Read for legacy,
+ * lz4stream/block.go:284-294: 8 MiB blocks, no checksums, no end mark; a size word
+ * equal to the legacy magic starts a concatenated frame; a size word equal to the
+ * bytes decoded so far ends the stream (Linux kernel appends the total size). */
+static int64_t legacy_uncompress(const uint8_t *src, size_t n, size_t si, uint8_t *dst,
+                                 size_t dst_cap) {
+    const uint32_t cap = 8u << 20;
+    size_t di = 0;
+    while (n - si >= 4) {
+        uint32_t x = ld32(src + si);
+        si += 4;
+        if (x == FRAME_MAGIC_LEGACY) continue;
+        if (x == (uint32_t)di) break; /* :289-293 */
+        uint32_t size = x & 0x7FFFFFFFu;
+        if (size > cap) return LZ4O_FE_BLOCK_SIZE;
+        if (n - si < size) return LZ4O_FE_TRUNCATED;
+        size_t room = dst_cap - di < cap ? dst_cap - di : cap;
+        int64_t got;
+        if (x >> 31) {
+            if (size > room) return LZ4O_FE_SHORT_BUFFER;
+            memcpy(dst + di, src + si, size);
+            got = size;
+        } else {
+            got = lz4o_uncompress_block(src + si, size, dst + di, room, NULL, 0);
+            if (got < 0) return LZ4O_FE_SHORT_BUFFER;
+        }
+        si += size;
+        di += (size_t)got;
+    }
+    return (int64_t)di;
+}
+
 int64_t lz4o_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_cap) {
     size_t si = 0;
     uint32_t magic;
@@ -614,7 +646,8 @@ int64_t lz4o_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size_t
             si += skip;
             continue;
         }
-        return LZ4O_FE_INVALID_FRAME; /* legacy frames are out of scope here */
+        if (magic == FRAME_MAGIC_LEGACY) return legacy_uncompress(src, n, si, dst, dst_cap);
+        return LZ4O_FE_INVALID_FRAME;
     }
     /* descriptor: frame.go:169-200 */
     if (n - si < 3) return LZ4O_FE_TRUNCATED;

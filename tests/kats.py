@@ -128,7 +128,7 @@ GOLDEN_FRAMES = {  # frame file -> (raw file, content checksum)
     "pg_control.tar.lz4": ("pg_control.tar", 0xdbd91b0a),
 }
 
-# Legacy-format golden (magic 0x184C2102, frame.go:20): out of scope this round.
+# Legacy-format golden (magic 0x184C2102, frame.go:20), made by the Linux kernel build.
 LEGACY_FRAME = "bzImage_lz4_isolated.lz4"
 
 # Candidate compressed sizes from SURVEY.md §6 (an independent throwaway
@@ -145,3 +145,26 @@ CANDIDATE_SIZES = {  # file -> (Fast, HC depth 512, HC depth 131072)
     "pi.txt": (98139, None, None),
     "Mark.Twain-Tom.Sawyer.txt": (226723, None, None),
 }
+
+
+def legacy_frames(compress_block):
+    """Synthetic legacy frames (lz4stream/block.go:279-317 legacy rules), built from
+    `compress_block(bytes) -> bytes`.  Returns [(name, frame, expected or None)]."""
+    import struct
+    magic = struct.pack("<I", 0x184C2102)
+    a = (b"legacy block one " * 500)[:7001]
+    b = bytes(range(256)) * 40
+    ca, cb = compress_block(a), compress_block(b)
+    blk = lambda c: struct.pack("<I", len(c)) + c
+    raw = lambda d: struct.pack("<I", len(d) | 0x80000000) + d
+    return [
+        ("two_blocks", magic + blk(ca) + blk(cb), a + b),
+        ("kernel_trailer", magic + blk(ca) + blk(cb) + struct.pack("<I", len(a) + len(b)), a + b),
+        ("trailer_then_garbage", magic + blk(ca) + struct.pack("<I", len(a)) + b"\xff" * 9, a),
+        ("concatenated", magic + blk(ca) + magic + blk(cb), a + b),
+        ("raw_block", magic + raw(b"abc" * 11) + blk(ca), b"abc" * 11 + a),
+        ("empty", magic, b""),
+        ("truncated_payload", magic + blk(ca) + blk(cb)[:-5], None),
+        ("oversize_word", magic + blk(ca) + struct.pack("<I", (8 << 20) + 1) + b"x" * 64, None),
+        ("bad_block", magic + struct.pack("<I", 6) + b"\xf0\x00\x00\x00\x00\x00", None),
+    ]

@@ -87,6 +87,28 @@ def test_golden_frames_decode_to_raw(frame):
     assert lz.Reader(io.BytesIO(load(frame))).Read() == raw
 
 
+def test_legacy_golden_frame():
+    """TestReaderLegacy (reader_test.go:192-236)."""
+    import lz4_amd as lz
+    raw = load("bzImage_lz4_isolated")
+    assert lz.Reader(io.BytesIO(load(kats.LEGACY_FRAME))).Read() == raw
+
+
+@pytest.mark.parametrize("i", range(9))
+def test_legacy_synthetic(i, oracle):
+    import lz4_amd as lz
+    name, frame, want = kats.legacy_frames(lambda d: oracle.CompressBlock(d, len(d) + 64)[1])[i]
+    if want is None:
+        with pytest.raises(Exception) as e:
+            lz.frame.uncompress_frame(frame)
+        with pytest.raises(ValueError):
+            oracle.frame_uncompress(frame, 1 << 20)
+        assert not isinstance(e.value, (AssertionError, TypeError)), name
+    else:
+        assert lz.frame.uncompress_frame(frame) == want, name
+        assert oracle.frame_uncompress(frame, 1 << 20) == want
+
+
 def test_malformed_block_checksum():
     """reader_test.go: malformed.block.lz4 => invalid block checksum."""
     import lz4_amd as lz

@@ -133,10 +133,25 @@ def test_golden_frames_decode_to_raw(frame):
         assert o.ChecksumZero(raw) == cs
 
 
-def test_legacy_frame_is_rejected_for_now():
-    with pytest.raises(ValueError) as e:
-        o.frame_uncompress(load(kats.LEGACY_FRAME), 1 << 21)
-    assert e.value.args[0] == -2  # LZ4O_FE_INVALID_FRAME
+def test_legacy_golden_frame_decodes_to_raw():
+    """TestReaderLegacy (reader_test.go:192-236): kernel-style legacy frame with the
+    trailing total-size word (lz4stream/block.go:289-293)."""
+    raw = load("bzImage_lz4_isolated")
+    assert o.frame_uncompress(load(kats.LEGACY_FRAME), len(raw) + 16) == raw
+
+
+def _legacy_cases():
+    return kats.legacy_frames(lambda d: o.CompressBlock(d, len(d) + 64)[1])
+
+
+@pytest.mark.parametrize("i", range(9))
+def test_legacy_synthetic(i):
+    name, frame, want = _legacy_cases()[i]
+    if want is None:
+        with pytest.raises(ValueError):
+            o.frame_uncompress(frame, 1 << 20)
+    else:
+        assert o.frame_uncompress(frame, 1 << 20) == want, name
 
 
 def test_malformed_block_checksum():
