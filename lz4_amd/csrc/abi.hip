@@ -74,13 +74,13 @@ uint32_t host_xxh32_short(const uint8_t *p, size_t n) {  // n < 16
 
 // Kernel generation of the Fast compressor: 3 = window-parallel with vector emission
 // (fast3.hip, default), 2 = window-parallel with scalar emission (fast2.hip),
-// 1 = step-serial (fast.hip).  LZ4HIP_FAST selects an older one for A/B runs.
+// 1 = step-serial (fast.hip), 4 = one lane per block (fast4.hip; needs one table per
+// block in the workspace, only pays with tens of thousands of blocks).  LZ4HIP_FAST
+// selects a non-default one for A/B runs; it is read on every call so that one
+// process can compare generations.
 int fast_generation() {
-    static const int g = [] {
-        const char *e = getenv("LZ4HIP_FAST");
-        return (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 3;
-    }();
-    return g;
+    const char *e = getenv("LZ4HIP_FAST");
+    return (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 3;
 }
 hipError_t launch_fast_any(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
                            uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,
@@ -131,6 +131,7 @@ size_t lz4hip_compress_bound(size_t n) { return n + n / 255 + 16; }
 
 size_t lz4hip_fast_workspace_bytes(size_t n_blocks) {
     if (n_blocks < kFastGlobalMinBlocks) return 0;  // LDS-table kernel, no workspace needed
+    if (fast_generation() == 4) return n_blocks * kFastSlotBytes;
     const size_t want = 4096;  // 16 waves per CU on 256 CUs
     return (n_blocks < want ? n_blocks : want) * kFastSlotBytes;
 }
@@ -156,6 +157,11 @@ int lz4hip_compress_fast_blocks(const void *d_src, size_t n, uint32_t block_size
     // Few blocks: one block per CU with the table in LDS finishes each block sooner.
     // Many blocks: global tables and many waves per CU give the higher throughput.
     if (nb < kFastGlobalMinBlocks) slots = 0;
+    if (fast_generation() == 4 && d_workspace && workspace_bytes / kFastSlotBytes >= nb && slots) {
+        HIPCHK(launch_fast4((const uint8_t *)d_src, n, block_size, nb, dst_mode, 0, (uint8_t *)d_dst,
+                            dst_stride, d_result, (uint16_t *)d_workspace, (hipStream_t)stream));
+        return LZ4HIP_OK;
+    }
     HIPCHK(launch_fast_any((const uint8_t *)d_src, n, block_size, nb, dst_mode, 0, (uint8_t *)d_dst,
                        dst_stride, d_result, (uint16_t *)d_workspace, slots,
                        (hipStream_t)stream));

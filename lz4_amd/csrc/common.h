@@ -70,6 +70,9 @@ hipError_t launch_fast2(const uint8_t *src, size_t n, uint32_t bs, size_t nb, in
 hipError_t launch_fast3(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
                         uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,
                         uint16_t *ws, size_t slots, hipStream_t st);
+hipError_t launch_fast4(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
+                        uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,
+                        uint16_t *ws, hipStream_t st);
 hipError_t launch_hc(const uint8_t *src, size_t n, uint32_t bs, size_t nb, uint32_t depth,
                      int dst_mode,
                      uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result, uint32_t *ws,

@@ -201,3 +201,19 @@ def test_fast_many_blocks_global_table_kernel(T, oracle):
     bs = 1 << 18
     data = corpus.generate("text", 7 << 20, 1100 * bs)
     _check_blocks(T, oracle, data, bs)
+
+
+@pytest.mark.parametrize("gen", ["1", "2", "4"])
+def test_fast_other_generations(T, oracle, gen, monkeypatch):
+    """LZ4HIP_FAST selects the older / experimental Fast kernels (read per call):
+    every generation must emit the oracle's bytes.  4 = one lane per block."""
+    from lz4_amd import corpus, device as dev
+    monkeypatch.setenv("LZ4HIP_FAST", gen)
+    monkeypatch.setattr(dev, "_ws_cache", {})
+    bs = 1 << 16
+    data = corpus.generate("mixed", 99, 1300 * bs + 4321)
+    _check_blocks(T, oracle, data, bs)
+    if gen == "4":  # ragged sizes, bound mode and tiny blocks through the lane kernel
+        data = corpus.generate("binary", 5 << 20, 1030 * (1 << 18) + 13)
+        _check_blocks(T, oracle, data, 1 << 18)
+    monkeypatch.setattr(dev, "_ws_cache", {})
