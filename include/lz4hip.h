@@ -60,6 +60,10 @@ extern "C" {
 #define LZ4HIP_F_CONTENT_CHECKSUM 2u
 #define LZ4HIP_F_CONTENT_SIZE 4u
 #define LZ4HIP_F_READFROM 8u
+/* LegacyOption(true) (options.go:230-242, frame.go:46-51,63-65): magic 0x184C2102
+ * only, 8 MiB blocks each compressed into an 8 MiB dst (lz4stream/block.go:226-227),
+ * no end mark, no content checksum; block_size and content_size are ignored. */
+#define LZ4HIP_F_LEGACY 16u
 
 const char *lz4hip_last_error(void);          /* thread-local text of the last failure */
 int lz4hip_device_count(void);                /* GPUs visible; 0 if none */
@@ -176,8 +180,10 @@ uint32_t lz4hip_xxh32(const uint8_t *p, size_t n);
 int64_t lz4hip_frame_compress(const uint8_t *src, size_t n, uint32_t block_size, uint32_t flags,
                               uint32_t level, uint64_t content_size, uint8_t *dst,
                               size_t dst_cap);
-/* io.ReadAll(lz4.NewReader(frame)) for a frame with independent blocks:
- * reader.go:81-196, lz4stream/block.go:279-340, frame.go:80-131,169-200.
+/* io.ReadAll(lz4.NewReader(frame)): reader.go:81-196, lz4stream/block.go:279-340,
+ * frame.go:80-131,169-200.  Independent blocks decode as one batch; linked blocks
+ * (FLG bit 5 clear) decode in stream order with the output so far as history
+ * (reader.go:176-189); legacy frames (magic 0x184C2102) per lz4stream/block.go:284-294.
  * Returns decoded length or a negative LZ4HIP_ERR_*. */
 int64_t lz4hip_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_cap);
 

@@ -17,4 +17,4 @@ from .block import (Block1Mb, Block4Mb, Block64Kb, Block256Kb, ChecksumZero,  # 
 from .frame import (BlockChecksumOption, BlockSizeOption, ChecksumOption,  # noqa: F401
                     CompressionLevelOption, ConcurrencyOption, ErrInvalidBlockChecksum,
                     ErrInvalidFrame, ErrInvalidFrameChecksum, ErrInvalidHeaderChecksum,
-                    ErrOptionInvalidBlockSize, Reader, SizeOption, Writer)
+                    ErrOptionInvalidBlockSize, LegacyOption, Reader, SizeOption, Writer)

@@ -15,7 +15,7 @@ OK, ERR_ARG, ERR_HIP, ERR_SHORT, ERR_FRAME = 0, -1, -2, -3, -4
 ERR_HEADER_CHECKSUM, ERR_BLOCK_SIZE, ERR_BLOCK_CHECKSUM, ERR_FRAME_CHECKSUM, ERR_BLOCK = -5, -6, -7, -8, -9
 
 DST_FRAME, DST_BOUND = 0, 1
-F_BLOCK_CHECKSUM, F_CONTENT_CHECKSUM, F_CONTENT_SIZE, F_READFROM = 1, 2, 4, 8
+F_BLOCK_CHECKSUM, F_CONTENT_CHECKSUM, F_CONTENT_SIZE, F_READFROM, F_LEGACY = 1, 2, 4, 8, 16
 
 # every symbol include/lz4hip.h declares: (restype, argtypes)
 _vp, _sz, _u32, _u64, _i64, _int = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int64, C.c_int

@@ -51,6 +51,7 @@ constexpr size_t kFastSlotBytes = 65536 * 2;    // one u16 table
 constexpr size_t kFastGlobalMinBlocks = 1024;   // below this the LDS-table kernel is used
 constexpr size_t kHcSlots = 2048;               // resident workgroups of the HC kernel
 constexpr size_t kHcSlotBytes = 2 * 65536 * 4;  // hashTable + chainTable
+constexpr uint32_t kLegacyBlock = 8u << 20;      // blocks.go:11, frame.go:49
 constexpr size_t kMaxSingleBlock = 1u << 30;    // int32 positions inside a block
 
 // Host xxh32 for the 2/10-byte frame descriptor only (frame.go:202-204).
@@ -293,9 +294,12 @@ size_t lz4hip_frame_trailer(uint8_t *dst, uint32_t flags, uint32_t content_xxh) 
 }
 
 size_t lz4hip_frame_bound(size_t n, uint32_t block_size, uint32_t flags) {
-    (void)flags;
-    const size_t nb = n / (block_size ? block_size : 1) + 2;
-    return 15 + n + nb * 8 + 8;
+    if (flags & LZ4HIP_F_LEGACY) block_size = kLegacyBlock;
+    const size_t bs = block_size ? block_size : 1;
+    const size_t nb = n / bs + 2;
+    // a legacy short last block is compressed into an 8 MiB dst and may grow to
+    // CompressBlockBound(len) instead of being stored raw
+    return 15 + n + nb * 8 + 8 + ((flags & LZ4HIP_F_LEGACY) ? n % bs / 255 + 16 : 0);
 }
 
 /* ---------------- host-pointer entry points ---------------- */
@@ -408,19 +412,34 @@ uint32_t lz4hip_xxh32(const uint8_t *p, size_t n) {
 int64_t lz4hip_frame_compress(const uint8_t *src, size_t n, uint32_t block_size, uint32_t flags,
                               uint32_t level, uint64_t content_size, uint8_t *dst,
                               size_t dst_cap) {
-    if (!valid_block_size(block_size)) return fail(LZ4HIP_ERR_BLOCK_SIZE, "invalid block size");
+    const bool legacy = flags & LZ4HIP_F_LEGACY;
+    if (legacy) block_size = kLegacyBlock;  // frame.go:47-50
+    else if (!valid_block_size(block_size)) return fail(LZ4HIP_ERR_BLOCK_SIZE, "invalid block size");
     if ((n && !src) || !dst) return fail(LZ4HIP_ERR_ARG, "null pointer");
     if (dst_cap < lz4hip_frame_bound(n, block_size, flags))
         return fail(LZ4HIP_ERR_SHORT, "dst_cap < lz4hip_frame_bound()");
-    const bool bsum = flags & LZ4HIP_F_BLOCK_CHECKSUM, csum = flags & LZ4HIP_F_CONTENT_CHECKSUM;
+    const bool bsum = flags & LZ4HIP_F_BLOCK_CHECKSUM;
+    const bool csum = (flags & LZ4HIP_F_CONTENT_CHECKSUM) && !legacy;  // frame.go:63-65
     const size_t nb_data = (n + block_size - 1) / block_size;
     // Close() flushes only pending bytes; ReadFrom writes data[:rn] even when rn == 0
-    // (writer.go:161-167 vs :220-233).
-    const size_t nb =
-        nb_data + (((flags & LZ4HIP_F_READFROM) && n % block_size == 0) ? 1 : 0);
+    // (writer.go:161-167 vs :220-233).  A standard frame stores that empty block raw
+    // (dst = data[:0]); a legacy frame compresses it into the 8 MiB dst, which yields
+    // the one-byte block 00 (lz4stream/block.go:226-227, block.go:258-292).
+    const bool empty_tail = (flags & LZ4HIP_F_READFROM) && n % block_size == 0;
+    const size_t nb = nb_data + ((empty_tail && !legacy) ? 1 : 0);
+    // dst_len of every block: len(src) in a standard frame, cap(data) = 8 MiB in a legacy one
+    const int dmode = legacy ? kDstExplicit : LZ4HIP_DST_FRAME;
+    const uint32_t dlen_x = legacy ? kLegacyBlock : 0;
 
-    uint8_t hdr[16], trl[8];
-    const size_t hlen = lz4hip_frame_header(hdr, block_size, flags, content_size);
+    uint8_t hdr[16], trl[12];
+    size_t hlen;
+    if (legacy) {  // magic only: frame.go:150-165
+        const uint32_t m = 0x184C2102u;
+        memcpy(hdr, &m, 4);
+        hlen = 4;
+    } else {
+        hlen = lz4hip_frame_header(hdr, block_size, flags, content_size);
+    }
 
     DevBuf d_src, d_comp, d_res, d_xxh, d_off, d_frame, d_cs, d_fws;
     hipStream_t s_main = nullptr, s_sum = nullptr;
@@ -452,7 +471,7 @@ int64_t lz4hip_frame_compress(const uint8_t *src, size_t n, uint32_t block_size,
             if (level == 0) {
                 const size_t wsb = lz4hip_fast_workspace_bytes(nb_data);
                 if (wsb) STEP(d_fws.alloc(wsb));
-                STEP(launch_fast_any(d_src.as<uint8_t>(), n, block_size, nb_data, LZ4HIP_DST_FRAME, 0,
+                STEP(launch_fast_any(d_src.as<uint8_t>(), n, block_size, nb_data, dmode, dlen_x,
                                  d_comp.as<uint8_t>(), block_size, d_res.as<int32_t>(),
                                  d_fws.as<uint16_t>(), wsb / kFastSlotBytes, s_main));
             } else {
@@ -460,7 +479,7 @@ int64_t lz4hip_frame_compress(const uint8_t *src, size_t n, uint32_t block_size,
                 const size_t slots = nb_data < kHcSlots ? nb_data : kHcSlots;
                 STEP(d_ws.alloc(slots * kHcSlotBytes));
                 STEP(launch_hc(d_src.as<uint8_t>(), n, block_size, nb_data, level,
-                               LZ4HIP_DST_FRAME, 0, d_comp.as<uint8_t>(), block_size,
+                               dmode, dlen_x, d_comp.as<uint8_t>(), block_size,
                                d_res.as<int32_t>(), d_ws.as<uint32_t>(), slots, s_main));
                 STEP(hipStreamSynchronize(s_main));  // d_ws dies with this scope
             }
@@ -481,7 +500,22 @@ int64_t lz4hip_frame_compress(const uint8_t *src, size_t n, uint32_t block_size,
         STEP(hipStreamSynchronize(s_sum));
         uint32_t cs = 0;
         if (csum) STEP(hipMemcpy(&cs, d_cs.p, 4, hipMemcpyDeviceToHost));
-        const size_t tlen = lz4hip_frame_trailer(trl, flags, cs);
+        size_t tlen;
+        if (legacy) {  // no end mark (frame.go:63-65); ReadFrom's empty block: size 1, token 00
+            tlen = 0;
+            if (empty_tail) {
+                const uint8_t one[5] = {1, 0, 0, 0, 0};
+                memcpy(trl, one, 5);
+                tlen = 5;
+                if (bsum) {  // xxh32("") = 0x02CC5D05 follows even here (lz4stream/block.go:248-250)
+                    const uint32_t e = 0x02CC5D05u;
+                    memcpy(trl + 5, &e, 4);
+                    tlen = 9;
+                }
+            }
+        } else {
+            tlen = lz4hip_frame_trailer(trl, flags, cs);
+        }
         if (end_off + tlen > dst_cap) {
             rc = fail(LZ4HIP_ERR_SHORT, "frame larger than dst_cap");
             break;
@@ -616,8 +650,6 @@ int64_t lz4hip_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size
     if (idx < 4) return fail(LZ4HIP_ERR_BLOCK_SIZE, "invalid block size");
     const uint32_t bs = 1u << (8 + 2 * idx);
     const bool bsum = f >> 4 & 1, csum = f >> 2 & 1, independent = f >> 5 & 1;
-    if (!independent)
-        return fail(LZ4HIP_ERR_ARG, "linked-block frames are not handled by the batched decoder");
 
     // ---- block index: lz4stream/block.go:279-317 (host walk over size words) ----
     std::vector<uint64_t> off;
@@ -662,10 +694,19 @@ int64_t lz4hip_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size
     HIPCHK(hipMemcpy(d_src.p, src, n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_off.p, off.data(), nb * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_sw.p, sw.data(), nb * 4, hipMemcpyHostToDevice));
-    HIPCHK(launch_decode_any(d_src.as<uint8_t>(), d_off.as<uint64_t>(), d_sw.as<uint32_t>(), nb,
-                         d_out.as<uint8_t>(), bs, bs, 0, d_len.as<int32_t>(), nullptr));
+    DevBuf d_ooff;  // linked frames: where each block's output starts in d_out
+    if (independent) {
+        HIPCHK(launch_decode_any(d_src.as<uint8_t>(), d_off.as<uint64_t>(), d_sw.as<uint32_t>(), nb,
+                                 d_out.as<uint8_t>(), bs, bs, 0, d_len.as<int32_t>(), nullptr));
+    } else {  // reader.go:86-90,176-189: dependent blocks decode in order, output packed
+        HIPCHK(d_ooff.alloc(nb * 8));
+        HIPCHK(launch_decode2_linked(d_src.as<uint8_t>(), d_off.as<uint64_t>(), d_sw.as<uint32_t>(),
+                                     nb, d_out.as<uint8_t>(), bs, d_len.as<int32_t>(),
+                                     d_ooff.as<uint64_t>(), nullptr));
+    }
     if (bsum)  // verified on the DECODED bytes: lz4stream/block.go:330-335
-        HIPCHK(launch_xxh32_blocks(d_out.as<uint8_t>(), nb * (size_t)bs, bs, nullptr,
+        HIPCHK(launch_xxh32_blocks(d_out.as<uint8_t>(), nb * (size_t)bs, bs,
+                                   independent ? nullptr : d_ooff.as<uint64_t>(),
                                    d_len.as<int32_t>(), nb, d_xxh.as<uint32_t>(), nullptr));
     std::vector<int32_t> len(nb);
     std::vector<uint32_t> got(nb);
@@ -673,11 +714,11 @@ int64_t lz4hip_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size
     if (bsum) HIPCHK(hipMemcpy(got.data(), d_xxh.p, nb * 4, hipMemcpyDeviceToHost));
     // first failing block wins, in stream order (lz4stream/block.go:187-194)
     size_t total = 0;
-    bool dense = true;  // every block but the last is full: one contiguous copy
+    bool dense = true;  // every block but the last is full (or packed): one contiguous copy
     for (size_t b = 0; b < nb; b++) {
         if (len[b] < 0) return fail(LZ4HIP_ERR_BLOCK, "invalid source or destination buffer too short");
         if (bsum && got[b] != want[b]) return fail(LZ4HIP_ERR_BLOCK_CHECKSUM, "invalid block checksum");
-        if (b + 1 < nb && (uint32_t)len[b] != bs) dense = false;
+        if (independent && b + 1 < nb && (uint32_t)len[b] != bs) dense = false;
         total += (size_t)len[b];
     }
     if (total > dst_cap) return fail(LZ4HIP_ERR_SHORT, "dst_cap too small");

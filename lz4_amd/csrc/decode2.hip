@@ -248,6 +248,61 @@ __global__ __launch_bounds__(64) void k_decode2(const uint8_t *__restrict__ src,
     if (lane == 0) out_len[b] = r;
 }
 
+// Linked-block frame (FLG bit 5 clear): every block may reference the 64 KiB of
+// output before it (reader.go:176-189 keeps that history as the dictionary), so the
+// blocks of one frame decode in stream order by ONE wave into one contiguous buffer,
+// where "the dictionary" is simply the output already written: prefix = bytes so far.
+// The reader's history holds at least min(bytes so far, 64 KiB) and offsets are
+// < 64 KiB, so `offset > di + len(dict)` fires exactly when `offset > di + prefix`.
+// out_off[b] = start of block b's output, out_len[b] = its length or -1; the walk
+// stops at the first bad block (later blocks report -1).
+__global__ __launch_bounds__(64) void k_decode2_linked(const uint8_t *__restrict__ src,
+                                                       const uint64_t *__restrict__ off,
+                                                       const uint32_t *__restrict__ sw, size_t nb,
+                                                       uint8_t *dst, uint32_t block_cap,
+                                                       int32_t *__restrict__ out_len,
+                                                       uint64_t *__restrict__ out_off) {
+    const int lane = lane_id();
+    size_t total = 0;
+    bool dead = false;
+    for (size_t b = 0; b < nb; b++) {
+        int r = -1;
+        if (!dead) {
+            const uint32_t w = sw[b];
+            const int n = (int)(w & 0x7FFFFFFFu);
+            const uint8_t *in = src + off[b];
+            uint8_t *d = dst + total;
+            if (w >> 31) {
+                r = (uint32_t)n > block_cap ? (int)block_cap : n;
+                wave_copy(d, in, r, lane);
+            } else if (n == 0) {
+                r = 0;
+            } else {
+                const int prefix = total > (size_t)kWinSize ? kWinSize : (int)total;
+                r = decode2_block(in, n, d, (int)block_cap, prefix, lane);
+            }
+            r = (int)rfl((uint32_t)r);
+            // this wave's stores must be visible to its own later loads
+            __threadfence();
+        }
+        if (lane == 0) {
+            out_len[b] = r;
+            out_off[b] = total;
+        }
+        if (r < 0) dead = true;
+        else total += (size_t)r;
+    }
+}
+
+hipError_t launch_decode2_linked(const uint8_t *src, const uint64_t *off, const uint32_t *sw,
+                                 size_t nb, uint8_t *dst, uint32_t block_cap, int32_t *out_len,
+                                 uint64_t *out_off, hipStream_t st) {
+    if (nb == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_decode2_linked, dim3(1), dim3(kWave), 0, st, src, off, sw, nb, dst,
+                       block_cap, out_len, out_off);
+    return hipGetLastError();
+}
+
 hipError_t launch_decode2(const uint8_t *src, const uint64_t *off, const uint32_t *sw, size_t nb,
                           uint8_t *dst, size_t dst_stride, uint32_t dst_len, uint32_t prefix,
                           int32_t *out_len, hipStream_t st) {

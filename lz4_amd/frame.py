@@ -111,6 +111,15 @@ def CompressionLevelOption(level):
     return opt
 
 
+def LegacyOption(legacy):
+    """options.go:222-242: legacy frame (magic 0x184C2102, 8 MiB blocks), Writer only"""
+    def opt(a):
+        if not isinstance(a, Writer):
+            raise ErrOptionNotApplicable()
+        a.legacy = bool(legacy)
+    return opt
+
+
 def _ro(b):
     if isinstance(b, np.ndarray):
         return np.ascontiguousarray(b, dtype=np.uint8)
@@ -118,7 +127,7 @@ def _ro(b):
 
 
 def compress_frame(data, block_size=1 << 22, block_checksum=False, content_checksum=True,
-                   content_size=0, level=Fast, readfrom=False):
+                   content_size=0, level=Fast, readfrom=False, legacy=False):
     """One frame for `data`: Writer.Write(data); Writer.Close()  (or io.Copy when
     readfrom=True: writer.go:199-242)."""
     _lib.require_gpu()
@@ -127,7 +136,8 @@ def compress_frame(data, block_size=1 << 22, block_checksum=False, content_check
     flags = ((_lib.F_BLOCK_CHECKSUM if block_checksum else 0)
              | (_lib.F_CONTENT_CHECKSUM if content_checksum else 0)
              | (_lib.F_CONTENT_SIZE if content_size > 0 else 0)
-             | (_lib.F_READFROM if readfrom else 0))
+             | (_lib.F_READFROM if readfrom else 0)
+             | (_lib.F_LEGACY if legacy else 0))
     cap = lib.lz4hip_frame_bound(s.size, block_size, flags)
     d = np.empty(cap, dtype=np.uint8)
     k = lib.lz4hip_frame_compress(s.ctypes.data if s.size else None, s.size, block_size, flags,
@@ -199,6 +209,7 @@ class Writer:
         self.content_size = 0
         self.level = Fast
         self.concurrency = 1
+        self.legacy = False
         self._buf = bytearray()
         self._readfrom = False
         self._closed = False
@@ -224,7 +235,7 @@ class Writer:
         self._closed = True
         self._w.write(compress_frame(self._buf, self.block_size, self.block_checksum,
                                      self.content_checksum, self.content_size, self.level,
-                                     self._readfrom))
+                                     self._readfrom, self.legacy))
 
     def Reset(self, w):
         self._w = w

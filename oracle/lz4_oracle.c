@@ -496,6 +496,7 @@ uint32_t lz4o_xxh32_sum32(const lz4o_xxh32_state *s) {
 #define FRAME_MAGIC 0x184D2204u        /* frame.go:18 */
 #define FRAME_SKIP_MAGIC 0x184D2A50u   /* frame.go:19 */
 #define FRAME_MAGIC_LEGACY 0x184C2102u /* frame.go:20 */
+#define LEGACY_BLOCK (8u << 20)         /* blocks.go:11 */
 
 /* blocks.go:22-36 */
 static int block_size_index(uint32_t bs) {
@@ -534,16 +535,21 @@ size_t lz4o_frame_header(uint8_t *dst, uint32_t block_size, uint32_t flags,
 }
 
 size_t lz4o_frame_bound(size_t n, uint32_t block_size, uint32_t flags) {
-    (void)flags;
+    if (flags & LZ4O_F_LEGACY) block_size = LEGACY_BLOCK;
     size_t nb = n / block_size + 2;
-    return 15 + n + nb * 8 + 8;
+    /* a legacy short last block may grow to CompressBlockBound(len) */
+    return 15 + n + nb * 8 + 8 + ((flags & LZ4O_F_LEGACY) ? n % block_size / 255 + 16 : 0);
 }
 
-/* lz4stream/block.go:224-276 for one block; returns bytes appended. */
+/* lz4stream/block.go:224-276 for one block; returns bytes appended.  legacy_tmp != NULL:
+ * legacy frame, dst = data[:cap(data)] = 8 MiB whatever len(src) is (:226-227), compressed
+ * into legacy_tmp (8 MiB) first because `out` need not have that much room. */
 static size_t frame_block(const uint8_t *src, size_t n, uint32_t level, uint32_t flags,
-                          uint8_t *out, uint32_t *size_word, uint32_t *xxh) {
-    int64_t r = level == 0 ? lz4o_compress_fast(src, n, out + 4, n)
-                           : lz4o_compress_hc(src, n, out + 4, n, level);
+                          uint8_t *out, uint32_t *size_word, uint32_t *xxh, uint8_t *legacy_tmp) {
+    uint8_t *cdst = legacy_tmp ? legacy_tmp : out + 4;
+    const size_t dlen = legacy_tmp ? (size_t)LEGACY_BLOCK : n;
+    int64_t r = level == 0 ? lz4o_compress_fast(src, n, cdst, dlen)
+                           : lz4o_compress_hc(src, n, cdst, dlen, level);
     uint32_t sw;
     size_t payload;
     if (r <= 0) { /* n == 0: incompressible or error => stored raw: :238-245 */
@@ -551,6 +557,7 @@ static size_t frame_block(const uint8_t *src, size_t n, uint32_t level, uint32_t
         payload = n;
         sw = (uint32_t)n | 0x80000000u;
     } else {
+        if (legacy_tmp) memcpy(out + 4, legacy_tmp, (size_t)r);
         payload = (size_t)r;
         sw = (uint32_t)r;
     }
@@ -571,24 +578,37 @@ static size_t frame_block(const uint8_t *src, size_t n, uint32_t level, uint32_t
 
 int64_t lz4o_frame_compress(const uint8_t *src, size_t n, uint32_t block_size, uint32_t flags,
                             uint32_t level, uint64_t content_size, uint8_t *dst, size_t dst_cap) {
-    if (!block_size_index(block_size)) return -1;
+    const int legacy = (flags & LZ4O_F_LEGACY) != 0;
+    if (legacy) block_size = LEGACY_BLOCK; /* frame.go:47-50 */
+    else if (!block_size_index(block_size)) return -1;
     if (dst_cap < lz4o_frame_bound(n, block_size, flags)) return -1;
-    size_t k = lz4o_frame_header(dst, block_size, flags, content_size);
+    uint8_t *tmp = NULL;
+    size_t k;
+    if (legacy) { /* magic only: frame.go:150-165 */
+        tmp = (uint8_t *)malloc(LEGACY_BLOCK);
+        if (!tmp) return -1;
+        st32(dst, FRAME_MAGIC_LEGACY);
+        k = 4;
+    } else {
+        k = lz4o_frame_header(dst, block_size, flags, content_size);
+    }
     lz4o_xxh32_state cs;
     memset(&cs, 0, sizeof cs);
     lz4o_xxh32_reset(&cs); /* frame.go:56 */
     size_t off = 0;
     while (n - off >= block_size) { /* full blocks: writer.go:88-119 / :220-233 */
-        k += frame_block(src + off, block_size, level, flags, dst + k, NULL, NULL);
+        k += frame_block(src + off, block_size, level, flags, dst + k, NULL, NULL, tmp);
         if (flags & LZ4O_F_CONTENT_CHECKSUM) lz4o_xxh32_write(&cs, src + off, block_size);
         off += block_size;
     }
     /* Close() flushes a short block only if bytes are pending (writer.go:161-167);
      * ReadFrom writes data[:rn] even when rn == 0 (writer.go:220-233). */
     if (n - off > 0 || (flags & LZ4O_F_READFROM)) {
-        k += frame_block(src + off, n - off, level, flags, dst + k, NULL, NULL);
+        k += frame_block(src + off, n - off, level, flags, dst + k, NULL, NULL, tmp);
         if (flags & LZ4O_F_CONTENT_CHECKSUM) lz4o_xxh32_write(&cs, src + off, n - off);
     }
+    free(tmp);
+    if (legacy) return (int64_t)k; /* no end mark, no content checksum: frame.go:63-65 */
     st32(dst + k, 0); /* end mark: frame.go:66-68 */
     k += 4;
     if (flags & LZ4O_F_CONTENT_CHECKSUM) {

@@ -77,6 +77,7 @@ uint32_t lz4o_xxh32_sum32(const lz4o_xxh32_state *s);
 #define LZ4O_F_BLOCK_CHECKSUM 1u   /* BlockChecksumOption(true) */
 #define LZ4O_F_CONTENT_CHECKSUM 2u /* ChecksumOption(true), the default */
 #define LZ4O_F_CONTENT_SIZE 4u     /* SizeOption(content_size) */
+#define LZ4O_F_LEGACY 16u          /* LegacyOption(true): options.go:230-242, frame.go:46-51 */
 #define LZ4O_F_READFROM 8u         /* entry point is Writer.ReadFrom / io.Copy (writer.go:199-242) */
 
 /* Frame descriptor: internal/lz4stream/frame.go:144-167,202-204, frame_gen.go:7-29.

@@ -19,6 +19,7 @@ F_BLOCK_CHECKSUM = 1
 F_CONTENT_CHECKSUM = 2
 F_CONTENT_SIZE = 4
 F_READFROM = 8
+F_LEGACY = 16
 
 
 class ErrInvalidSourceShortBuffer(Exception):

@@ -168,3 +168,108 @@ def legacy_frames(compress_block):
         ("oversize_word", magic + blk(ca) + struct.pack("<I", (8 << 20) + 1) + b"x" * 64, None),
         ("bad_block", magic + struct.pack("<I", 6) + b"\xf0\x00\x00\x00\x00\x00", None),
     ]
+
+
+# Goldens made by the C lz4 tool from one 4,266,361-byte text (reader_test.go:40-46): the
+# same content as 4 MiB independent blocks and as 64 KiB LINKED blocks.  The raw file is
+# not shipped by the reference; both frames carry its XXH32 as their content checksum.
+LONG_FRAMES = {
+    "Mark.Twain-Tom.Sawyer_long.txt.lz4": (4266361, 0x788577F8),
+    "Mark.Twain-Tom.Sawyer_linked.txt.lz4": (4266361, 0x788577F8),
+}
+
+
+def emit_seq(lit, offset=0, mlen=0):
+    """One LZ4 sequence (decode_test.go emitSeq): literals then, when mlen >= 4, a match."""
+    out = bytearray()
+    ll = len(lit)
+    ml = mlen - 4 if mlen else 0
+    out.append((min(ll, 15) << 4) | (min(ml, 15) if mlen else 0))
+    if ll >= 15:
+        r = ll - 15
+        out += b"\xff" * (r // 255) + bytes([r % 255])
+    out += lit
+    if mlen:
+        out += bytes([offset & 0xFF, offset >> 8])
+        if ml >= 15:
+            r = ml - 15
+            out += b"\xff" * (r // 255) + bytes([r % 255])
+    return bytes(out)
+
+
+def linked_frames(xxh32):
+    """Hand-built LINKED-block frames (FLG bit 5 clear; reader.go:176-189).
+    `xxh32(bytes) -> int`.  Returns [(name, frame, expected bytes or None for an error)]."""
+    import struct
+
+    def frame(blocks, bsum=False, csum=False, expect=b"", bad_cs=False):
+        flg = 0x40 | (0x10 if bsum else 0) | (0x04 if csum else 0)
+        hdr = bytes([flg, 0x40])
+        out = struct.pack("<I", 0x184D2204) + hdr + bytes([(xxh32(hdr) >> 8) & 0xFF])
+        for payload, raw, decoded in blocks:
+            out += struct.pack("<I", len(payload) | (0x80000000 if raw else 0)) + payload
+            if bsum:
+                x = xxh32(decoded)
+                if x:
+                    out += struct.pack("<I", x)
+        out += struct.pack("<I", 0)
+        if csum:
+            out += struct.pack("<I", xxh32(expect) ^ (1 if bad_cs else 0))
+        return out
+
+    a = bytes(range(97, 123)) * 3                       # 78 bytes of history
+    b1 = emit_seq(a)
+    # block 2: 5 literals, then 20 bytes from 30 bytes back (all inside block 1)
+    b2 = emit_seq(b"HELLO", 30 + 5, 20) + emit_seq(b"tail!")
+    d2 = b"HELLO" + a[-30:-10] + b"tail!"
+    # block 3: match that starts in the history and runs over its own output (overlap)
+    b3 = emit_seq(b"", 3, 40) + emit_seq(b"end..")
+    h3 = a + d2
+    d3 = bytearray()
+    for k in range(40):
+        d3.append((h3 + bytes(d3))[len(h3) + k - 3])
+    d3 = bytes(d3) + b"end.."
+    raw4 = b"RAWBLOCK" * 4
+    b5 = emit_seq(b"", len(raw4), 12) + emit_seq(b"12345")
+    d5 = raw4[:12] + b"12345"
+    blocks = [(b1, False, a), (b2, False, d2), (b3, False, d3)]
+    full = a + d2 + d3
+    out = [
+        ("three_blocks", frame(blocks, expect=full), full),
+        ("all_checksums", frame(blocks, bsum=True, csum=True, expect=full), full),
+        ("raw_block_as_history",
+         frame(blocks + [(raw4, True, raw4), (b5, False, d5)], bsum=True, csum=True,
+               expect=full + raw4 + d5), full + raw4 + d5),
+        ("bad_content_checksum", frame(blocks, csum=True, expect=full, bad_cs=True), None),
+        ("offset_before_history", frame([(b1, False, a), (emit_seq(b"x", 80, 4) + emit_seq(b"yyyyy"), False, b"")]), None),
+        ("first_block_needs_history", frame([(emit_seq(b"ab", 3, 4) + emit_seq(b"yyyyy"), False, b"")]), None),
+    ]
+    # far history: 70,000 bytes of filler, then a match 65,535 back
+    filler1 = bytes((i * 7 + 3) & 0xFF for i in range(60000))
+    filler2 = bytes((i * 13 + 5) & 0xFF for i in range(10000))
+    far = emit_seq(b"Z", 65535, 8) + emit_seq(b"done.")
+    hist = filler1 + filler2 + b"Z"
+    dfar = b"Z" + hist[len(hist) - 65535:len(hist) - 65535 + 8] + b"done."
+    out.append(("offset_65535", frame([(emit_seq(filler1), False, filler1), (emit_seq(filler2), False, filler2),
+                                       (far, False, dfar)], csum=True, expect=filler1 + filler2 + dfar),
+                filler1 + filler2 + dfar))
+    return out
+
+
+def legacy_write_cases(load):
+    """Inputs for LegacyOption(true) (writer_test.go:256-299 + edge cases):
+    [(name, data, readfrom, level, block_checksum)]."""
+    import numpy as np
+    bz = load("bzImage_lz4_isolated")
+    rnd = np.random.default_rng(7).integers(0, 256, 2 * (8 << 20), dtype=np.uint8).tobytes()
+    return [
+        ("bzImage_write", bz, False, 0, False),
+        ("bzImage_iocopy", bz, True, 0, False),
+        ("empty_write", b"", False, 0, False),
+        ("empty_iocopy", b"", True, 0, False),
+        ("short_incompressible", rnd[:100], False, 0, False),       # grows: 102 bytes, not raw
+        ("two_raw_blocks_iocopy", rnd, True, 0, False),             # raw blocks + 01 00 00 00 00
+        ("block_and_tail", (bz * 9)[:(8 << 20) + 12345], False, 0, False),
+        ("exact_block_iocopy", (bz * 9)[:8 << 20], True, 0, True),
+        ("hc_level", bz[:300000], False, 1 << 9, False),
+    ]

@@ -109,6 +109,50 @@ def test_legacy_synthetic(i, oracle):
         assert oracle.frame_uncompress(frame, 1 << 20) == want
 
 
+@pytest.mark.parametrize("name", sorted(kats.LONG_FRAMES))
+def test_long_and_linked_goldens(name, oracle):
+    """reader_test.go:40-46; the linked frame decodes serially on the device."""
+    import lz4_amd as lz
+    size, cs = kats.LONG_FRAMES[name]
+    out = lz.Reader(io.BytesIO(load(name))).Read()
+    assert len(out) == size and lz.ChecksumZero(out) == cs
+    assert out == oracle.frame_uncompress(load(name), size + 16)
+
+
+@pytest.mark.parametrize("i", range(7))
+def test_linked_synthetic(i, oracle):
+    import lz4_amd as lz
+    name, frame, want = kats.linked_frames(oracle.ChecksumZero)[i]
+    if want is None:
+        with pytest.raises(ValueError):
+            oracle.frame_uncompress(frame, 1 << 20)
+        with pytest.raises(Exception) as e:
+            lz.frame.uncompress_frame(frame)
+        assert not isinstance(e.value, (AssertionError, TypeError)), name
+    else:
+        assert lz.frame.uncompress_frame(frame) == want, name
+
+
+@pytest.mark.parametrize("i", range(9))
+def test_legacy_write(i, oracle):
+    """TestWriterLegacy (writer_test.go:256-299): bytes equal the oracle's, and read back."""
+    import lz4_amd as lz
+    name, data, readfrom, level, bsum = kats.legacy_write_cases(load)[i]
+    out = io.BytesIO()
+    zw = lz.Writer(out)
+    zw.Apply(lz.LegacyOption(True), lz.CompressionLevelOption(level), lz.BlockChecksumOption(bsum))
+    if readfrom:
+        zw.ReadFrom(io.BytesIO(data))
+    else:
+        zw.Write(data)
+    zw.Close()
+    flags = (oracle.F_LEGACY | (oracle.F_READFROM if readfrom else 0)
+             | (oracle.F_BLOCK_CHECKSUM if bsum else 0))
+    assert out.getvalue() == oracle.frame_compress(data, flags=flags, level=level), name
+    if not bsum:
+        assert lz.Reader(io.BytesIO(out.getvalue())).Read() == data
+
+
 def test_malformed_block_checksum():
     """reader_test.go: malformed.block.lz4 => invalid block checksum."""
     import lz4_amd as lz

@@ -154,6 +154,45 @@ def test_legacy_synthetic(i):
         assert o.frame_uncompress(frame, 1 << 20) == want, name
 
 
+@pytest.mark.parametrize("name", sorted(kats.LONG_FRAMES))
+def test_long_and_linked_goldens(name):
+    """reader_test.go:40-46: 4 MiB independent blocks / 64 KiB linked blocks."""
+    import xxhash
+    size, cs = kats.LONG_FRAMES[name]
+    out = o.frame_uncompress(load(name), size + 16)
+    assert len(out) == size and xxhash.xxh32(out).intdigest() == cs
+
+
+@pytest.mark.parametrize("i", range(7))
+def test_linked_synthetic(i):
+    name, frame, want = kats.linked_frames(o.ChecksumZero)[i]
+    if want is None:
+        with pytest.raises(ValueError):
+            o.frame_uncompress(frame, 1 << 20)
+    else:
+        assert o.frame_uncompress(frame, 1 << 20) == want, name
+
+
+@pytest.mark.parametrize("i", range(9))
+def test_legacy_write_round_trip(i):
+    """TestWriterLegacy (writer_test.go:256-299): LegacyOption frames read back."""
+    name, data, readfrom, level, bsum = kats.legacy_write_cases(load)[i]
+    flags = o.F_LEGACY | (o.F_READFROM if readfrom else 0) | (o.F_BLOCK_CHECKSUM if bsum else 0)
+    f = o.frame_compress(data, flags=flags | o.F_CONTENT_CHECKSUM, level=level)
+    assert f[:4] == bytes.fromhex("02214c18")
+    assert f == o.frame_compress(data, flags=flags, level=level)   # content checksum ignored
+    if name == "empty_write":
+        assert len(f) == 4
+    if name == "empty_iocopy":
+        assert f[4:] == bytes([1, 0, 0, 0, 0])
+    if name == "short_incompressible":
+        assert f[4:8] == bytes([102, 0, 0, 0])
+    if name == "two_raw_blocks_iocopy":
+        assert f[4:8] == bytes.fromhex("00008080") and f[-5:] == bytes([1, 0, 0, 0, 0])
+    if not bsum:   # a legacy frame with block checksums is written but cannot be read back
+        assert o.frame_uncompress(f, len(data) + 16) == data
+
+
 def test_malformed_block_checksum():
     with pytest.raises(ValueError) as e:
         o.frame_uncompress(load("malformed.block.lz4"), 1 << 22)
