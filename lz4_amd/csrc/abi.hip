@@ -93,16 +93,19 @@ hipError_t launch_fast_any(const uint8_t *src, size_t n, uint32_t bs, size_t nb,
     }
 }
 
-// Decoder generation: 2 = window-parallel two-pass (decode2.hip, default), 1 = serial walk.
+// Decoder generation: 3 = window-parallel two-pass with the window's output staged in
+// LDS (decode3.hip, default), 2 = the same with direct stores (decode2.hip), 1 = serial
+// walk (decode.hip).  LZ4HIP_DECODE selects an older one for A/B runs (read per call).
 hipError_t launch_decode_any(const uint8_t *src, const uint64_t *off, const uint32_t *sw, size_t nb,
                              uint8_t *dst, size_t dst_stride, uint32_t dst_len, uint32_t prefix,
                              int32_t *out_len, hipStream_t st) {
-    static const int g = [] {
-        const char *e = getenv("LZ4HIP_DECODE");
-        return (e && e[0] == '1') ? 1 : 2;
-    }();
-    return g == 1 ? launch_decode(src, off, sw, nb, dst, dst_stride, dst_len, prefix, out_len, st)
-                  : launch_decode2(src, off, sw, nb, dst, dst_stride, dst_len, prefix, out_len, st);
+    const char *e = getenv("LZ4HIP_DECODE");
+    const int g = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 3;
+    switch (g) {
+    case 1: return launch_decode(src, off, sw, nb, dst, dst_stride, dst_len, prefix, out_len, st);
+    case 2: return launch_decode2(src, off, sw, nb, dst, dst_stride, dst_len, prefix, out_len, st);
+    default: return launch_decode3(src, off, sw, nb, dst, dst_stride, dst_len, prefix, out_len, st);
+    }
 }
 
 // RAII device buffer for the host-pointer entry points.

@@ -1,9 +1,12 @@
 import sys, time, torch, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lz4_amd import corpus, device as dev
 dv = torch.device('cuda', 0)
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
+only = sys.argv[2] if len(sys.argv) > 2 else None
 for kind, BS in (('text', 1 << 16), ('mixed', 1 << 18)):
+    if only and kind != only:
+        continue
     n = int(gib * (1 << 30))
     src = corpus.generate_device(kind, n, dv)
     nb = n // BS
