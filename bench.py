@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 from lz4_amd import _lib, corpus, device as dev  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+RANDOM_RW_PEAK_GREQ = 40.3  # profiles/r1_random_access_microbench.txt: rd+wr, 8 GiB footprint
 
 
 def parse():
@@ -195,6 +196,20 @@ def main():
     if rank == 0:
         total = args.steps * 2 * n * world
         alg_bytes = n + c_mixed + 8 * nb_c  # N read + C written + 8 B/block
+        # HBM-side traffic of the dominant kernel from the committed PMC passes of this
+        # same workload (profiles/traffic.json: per-input-byte figures, tools/pmc_bench.sh);
+        # a launch's traffic is those figures times the launch's input bytes.
+        traffic, ra = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                tj = json.load(f)["k_fast3_gtab"]
+            traffic = round(tj["traffic_bytes_per_byte"] * n)
+            req = (tj["read_requests_per_byte"] + tj["write_requests_per_byte"]) * n
+            ra = {"achieved_Greq_s": round(req / t_comp / 1e9, 2), "peak_Greq_s": RANDOM_RW_PEAK_GREQ,
+                  "frac": round(req / t_comp / 1e9 / RANDOM_RW_PEAK_GREQ, 3),
+                  "note": "random 2-byte table get+put; peak = tools/micro/randacc.hip rd+wr at 8 GiB footprint"}
+        except (OSError, KeyError, ValueError):
+            pass
         line = {
             "metric": "GB/s uncompressed (node) for Fast compress + decompress",
             "value": round(total / dt / 1e9, 3),
@@ -223,7 +238,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_fast3_gtab",
                          "achieved": round(alg_bytes / t_comp / 1e9, 3), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(alg_bytes / t_comp / 1e9 / HBM_PEAK_GBPS, 5),
-                         "traffic": None,
+                         "traffic": traffic, "random_access": ra,
                          "decode_achieved": round((n + c_text) / t_dec / 1e9, 3),
                          "decode_frac": round((n + c_text) / t_dec / 1e9 / HBM_PEAK_GBPS, 5)},
             "cpu_baseline": cpu,

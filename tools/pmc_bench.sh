@@ -8,7 +8,7 @@ R=$PWD
 export TMPDIR=/tmp
 OUT=$R/gpurun_out/pmc_bench_$TAG
 mkdir -p $OUT
-run() { name=$1; shift; timeout -s KILL 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline $BENCH_ARGS > $OUT/$name.log 2>&1; }
+run() { name=$1; shift; timeout -s KILL 300 rocprofv3 --kernel-include-regex "lz4hip" --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline $BENCH_ARGS > $OUT/$name.log 2>&1; }
 BENCH_ARGS="$*"
 cd /tmp
 run ea TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
