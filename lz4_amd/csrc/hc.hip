@@ -80,7 +80,11 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                 const int lim = sn - si;
                 int next = (int)hash_table[h];
                 uint32_t tries = depth;
-                while (tries > 0 && next > 0 && si - next < kWinSize) {
+                // A prefix length never exceeds lim rounded up to 8 (:363-372) and only a
+                // strictly longer candidate replaces the winner (:373), so the walk can
+                // stop once that maximum is reached: the rest of the chain changes nothing.
+                const int ml_max = (lim + 7) & ~7;
+                while (tries > 0 && next > 0 && si - next < kWinSize && m_len < ml_max) {
                     // collect up to 64 chain entries, one per lane
                     int mine = 0, cnt = 0;
                     while (cnt < kWave && tries > 0 && next > 0 && si - next < kWinSize) {

@@ -1,5 +1,5 @@
 import sys, time, torch, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lz4_amd import corpus, device as dev
 from oracle import pyoracle as o
 dv = torch.device('cuda', 0)
