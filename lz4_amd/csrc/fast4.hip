@@ -137,6 +137,15 @@ __device__ int fast4_block(const uint8_t *__restrict__ s, int n, uint8_t *__rest
                         break;
                     }
                     si += 8;
+                    // long matches: four strides per round trip while they fit
+                    while (si + 32 <= sn) {
+                        const uint64_t x0 = ld64(s + si) ^ ld64(s + si - offset);
+                        const uint64_t x1 = ld64(s + si + 8) ^ ld64(s + si + 8 - offset);
+                        const uint64_t x2 = ld64(s + si + 16) ^ ld64(s + si + 16 - offset);
+                        const uint64_t x3 = ld64(s + si + 24) ^ ld64(s + si + 24 - offset);
+                        if (x0 | x1 | x2 | x3) break;
+                        si += 32;
+                    }
                     if (si + 8 > sn) break;
                     x = ld64(s + si) ^ ld64(s + si - offset);
                 }
