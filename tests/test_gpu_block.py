@@ -113,3 +113,49 @@ def test_small_inputs_all_dst_sizes(oracle):
                 for hc in (None, 7):
                     assert _gpu_compress(lz, src, dst_len, hc) == _cpu_compress(oracle, src, dst_len, hc), \
                         (n, alpha, dst_len, hc)
+
+
+def test_host_entry_points_from_many_threads(oracle):
+    """The package-level Go functions are goroutine-safe (block.go:96,310) and cgo runs
+    every call on its caller's OS thread: the host-pointer entry points must be
+    re-entrant.  8 threads mix Fast, HC, decode and xxh32 calls; every result must be
+    the oracle's."""
+    import threading
+    import lz4_amd as lz
+    from lz4_amd import corpus
+    rng = np.random.default_rng(11)
+    jobs = []
+    for i in range(24):
+        kind = ("text", "binary", "mixed")[i % 3]
+        n = int(rng.integers(1, 200000))
+        data = corpus.generate(kind, int(rng.integers(0, 1 << 24)), n).tobytes()
+        jobs.append(data)
+    want = []
+    for d in jobs:
+        k, pl = oracle.CompressBlock(d, oracle.CompressBlockBound(len(d)))
+        k2, pl2 = oracle.CompressBlockHC(d[:20000], 16, oracle.CompressBlockBound(min(len(d), 20000)))
+        want.append((pl, pl2, oracle.ChecksumZero(d)))
+    errors = []
+
+    def work(tid):
+        try:
+            for j in range(tid, len(jobs), 8):
+                d = jobs[j]
+                dst = bytearray(lz.CompressBlockBound(len(d)))
+                k = lz.CompressBlock(d, dst)
+                assert bytes(dst[:k]) == want[j][0], ("fast", j)
+                back = bytearray(len(d))
+                assert lz.UncompressBlock(bytes(dst[:k]), back) == len(d) and bytes(back) == d, ("decode", j)
+                dst2 = bytearray(lz.CompressBlockBound(min(len(d), 20000)))
+                k2 = lz.CompressBlockHC(d[:20000], dst2, 16)
+                assert bytes(dst2[:k2]) == want[j][1], ("hc", j)
+                assert lz.ChecksumZero(d) == want[j][2], ("xxh32", j)
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
