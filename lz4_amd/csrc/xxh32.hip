@@ -94,22 +94,79 @@ __global__ __launch_bounds__(64) void k_xxh32_blocks(const uint8_t *__restrict__
     out[i] = xxh32_span(base + o, l, (uint32_t)l);
 }
 
+// ---- content checksum: one stream, serial by construction ----
+//
+// Each accumulator is the chain v <- rol(v + x*P2, 13) * P1 over every 4th word of the
+// stream (xxh32zero.go:66-86); rotation makes it non-linear, so the chain cannot be
+// split or prefix-summed.  What can be taken off the chain is everything else: a wave
+// loads 64 stripes (1 KiB) with one coalesced load, all lanes multiply their words by
+// P2 in parallel and publish them transposed in LDS, and lanes 0..3 -- one accumulator
+// each -- run the 64-step add/rotate/multiply chain from LDS while the next chunk's
+// loads are already in flight.  The chain is then the only serial cost: about 25
+// cycles per 16-byte stripe.
+__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// v: accumulator `lane` in lanes 0..3.  y: 256 words of LDS.
+__device__ __forceinline__ uint32_t wave_accumulate(const uint8_t *__restrict__ p, size_t stripes,
+                                                    uint32_t v, int lane, uint32_t *y) {
+    const size_t chunks = stripes / kWave;
+    uint64_t a = 0, b = 0;
+    if (chunks) {
+        a = ld64(p + lane * 16);
+        b = ld64(p + lane * 16 + 8);
+    }
+    for (size_t c = 0; c < chunks; c++) {
+        y[lane] = (uint32_t)a * P2;
+        y[64 + lane] = (uint32_t)(a >> 32) * P2;
+        y[128 + lane] = (uint32_t)b * P2;
+        y[192 + lane] = (uint32_t)(b >> 32) * P2;
+        if (c + 1 < chunks) {  // next chunk's loads fly during the chain below
+            const uint8_t *q = p + (c + 1) * (size_t)(kWave * 16) + lane * 16;
+            a = ld64(q);
+            b = ld64(q + 8);
+        }
+        lds_sync();
+        if (lane < 4) {
+            const uint4 *row = reinterpret_cast<const uint4 *>(y + lane * 64);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint4 t = row[k];
+                v = rol(v + t.x, 13) * P1;
+                v = rol(v + t.y, 13) * P1;
+                v = rol(v + t.z, 13) * P1;
+                v = rol(v + t.w, 13) * P1;
+            }
+        }
+        lds_sync();
+    }
+    if (lane < 4)
+        for (size_t k = chunks * kWave; k < stripes; k++) v = xround(v, ld32(p + k * 16 + lane * 4));
+    return v;
+}
+
+__device__ __forceinline__ uint32_t merge_accumulators(uint32_t v) {
+    return rol(__shfl(v, 0), 1) + rol(__shfl(v, 1), 7) + rol(__shfl(v, 2), 12) + rol(__shfl(v, 3), 18);
+}
+
 // Content checksum: XXHZero over the whole stream.  Sum32 tests uint32(totalLen)
 // >= 16 (xxh32zero.go:113-118), so a stream of 2^32*k + r bytes with r < 16
 // takes the short branch and drops the accumulators; reproduced here.
 __global__ __launch_bounds__(64) void k_xxh32_stream(const uint8_t *__restrict__ src, size_t n,
                                                      uint32_t *__restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __shared__ __attribute__((aligned(16))) uint32_t y[256];
+    if (blockIdx.x != 0) return;
+    const int lane = lane_id();
     const uint32_t len_word = (uint32_t)n;
-    uint32_t h;
-    if (n >= 16 && len_word < 16) {
-        // accumulators ignored; the tail is still the last n % 16 buffered bytes
-        const size_t i = n - (n & 15);
-        h = xtail(len_word + P5, src + i, n - i);
+    const size_t stripes = n / 16;
+    uint32_t h = len_word;
+    if (len_word >= 16) {
+        const uint32_t init = lane == 0 ? P1 + P2 : lane == 1 ? P2 : lane == 2 ? 0u : 0u - P1;
+        h += merge_accumulators(wave_accumulate(src, stripes, init, lane, y));
     } else {
-        h = xxh32_span(src, n, len_word);
+        h += P5;  // n < 16, or the truncation quirk: accumulators ignored
     }
-    out[0] = h;
+    // the tail is the last n % 16 buffered bytes either way
+    if (lane == 0) out[0] = xtail(h, src + stripes * 16, n - stripes * 16);
 }
 
 // Chained form of the content checksum for a stream cut across GPUs: state =
@@ -119,37 +176,32 @@ __global__ __launch_bounds__(64) void k_xxh32_update(const uint8_t *__restrict__
                                                      uint32_t *__restrict__ state, int first,
                                                      int final_piece,
                                                      uint32_t *__restrict__ digest) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t v1, v2, v3, v4;
+    __shared__ __attribute__((aligned(16))) uint32_t y[256];
+    if (blockIdx.x != 0) return;
+    const int lane = lane_id();
+    uint32_t v;
     uint64_t total;
     if (first) {  // Reset(): xxh32zero.go:37-44
-        v1 = P1 + P2; v2 = P2; v3 = 0; v4 = 0u - P1; total = 0;
+        v = lane == 0 ? P1 + P2 : lane == 1 ? P2 : lane == 2 ? 0u : 0u - P1;
+        total = 0;
     } else {
-        v1 = state[0]; v2 = state[1]; v3 = state[2]; v4 = state[3];
+        v = state[lane & 3];
         total = (uint64_t)state[4] | ((uint64_t)state[5] << 32);
     }
     const size_t stripes = n / 16;
-    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-        const uint4 *q = reinterpret_cast<const uint4 *>(src);
-        for (size_t k = 0; k < stripes; k++) {
-            const uint4 a = q[k];
-            v1 = xround(v1, a.x); v2 = xround(v2, a.y); v3 = xround(v3, a.z); v4 = xround(v4, a.w);
-        }
-    } else {
-        for (size_t k = 0; k < stripes; k++) {
-            const uint8_t *p = src + k * 16;
-            v1 = xround(v1, ld32(p)); v2 = xround(v2, ld32(p + 4));
-            v3 = xround(v3, ld32(p + 8)); v4 = xround(v4, ld32(p + 12));
-        }
-    }
+    v = wave_accumulate(src, stripes, v, lane, y);
     total += n;
-    state[0] = v1; state[1] = v2; state[2] = v3; state[3] = v4;
-    state[4] = (uint32_t)total; state[5] = (uint32_t)(total >> 32);
+    if (lane < 4) state[lane] = v;
+    if (lane == 0) {
+        state[4] = (uint32_t)total;
+        state[5] = (uint32_t)(total >> 32);
+    }
     if (final_piece) {  // Sum32(): xxh32zero.go:112-139 incl. the uint32 truncation
         uint32_t h = (uint32_t)total;
-        if (h >= 16) h += rol(v1, 1) + rol(v2, 7) + rol(v3, 12) + rol(v4, 18);
+        const uint32_t m = merge_accumulators(v);
+        if (h >= 16) h += m;
         else h += P5;
-        digest[0] = xtail(h, src + stripes * 16, n - stripes * 16);
+        if (lane == 0) digest[0] = xtail(h, src + stripes * 16, n - stripes * 16);
     }
 }
 
