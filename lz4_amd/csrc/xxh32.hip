@@ -169,6 +169,38 @@ __global__ __launch_bounds__(64) void k_xxh32_stream(const uint8_t *__restrict__
     if (lane == 0) out[0] = xtail(h, src + stripes * 16, n - stripes * 16);
 }
 
+// One WAVE per span (few long spans: a frame of a handful of 4 MiB blocks, the
+// single-block ChecksumZero entry point): the same cooperative accumulate.
+__global__ __launch_bounds__(64) void k_xxh32_spans_wave(const uint8_t *__restrict__ base, size_t n,
+                                                         size_t stride,
+                                                         const uint64_t *__restrict__ off,
+                                                         const int32_t *__restrict__ len,
+                                                         size_t n_spans,
+                                                         uint32_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint32_t y[256];
+    const size_t i = blockIdx.x;
+    if (i >= n_spans) return;
+    const int lane = lane_id();
+    const size_t o = off ? (size_t)off[i] : i * stride;
+    size_t l;
+    if (len) {
+        l = len[i] < 0 ? 0 : (size_t)len[i];
+    } else {
+        const size_t left = n > o ? n - o : 0;
+        l = left < stride ? left : stride;
+    }
+    const uint8_t *p = base + o;
+    const size_t stripes = l / 16;
+    uint32_t h = (uint32_t)l;
+    if (l >= 16) {
+        const uint32_t init = lane == 0 ? P1 + P2 : lane == 1 ? P2 : lane == 2 ? 0u : 0u - P1;
+        h += merge_accumulators(wave_accumulate(p, stripes, init, lane, y));
+    } else {
+        h += P5;
+    }
+    if (lane == 0) out[i] = xtail(h, p + stripes * 16, l - stripes * 16);
+}
+
 // Chained form of the content checksum for a stream cut across GPUs: state =
 // {v1, v2, v3, v4, totalLen lo, totalLen hi}.  Non-final pieces must be multiples
 // of 16 bytes (block sizes are), so no carry buffer travels (xxh32zero.go:58-86).
@@ -216,6 +248,13 @@ hipError_t launch_xxh32_blocks(const uint8_t *base, size_t n, size_t stride, con
                                const int32_t *len, size_t n_spans, uint32_t *out,
                                hipStream_t st) {
     if (n_spans == 0) return hipSuccess;
+    // Few spans: a lane per span leaves the chip empty and each lane latency-bound;
+    // a wave per span streams its span at the accumulator chain's speed instead.
+    if (n_spans < 16384) {
+        hipLaunchKernelGGL(k_xxh32_spans_wave, dim3((unsigned)n_spans), dim3(kWave), 0, st, base, n,
+                           stride, off, len, n_spans, out);
+        return hipGetLastError();
+    }
     const unsigned grid = (unsigned)((n_spans + kWave - 1) / kWave);
     hipLaunchKernelGGL(k_xxh32_blocks, dim3(grid), dim3(kWave), 0, st, base, n, stride, off, len,
                        n_spans, out);
