@@ -48,7 +48,7 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 constexpr size_t kFastSlots = 8192;             // resident waves of the global-table Fast kernel
 constexpr size_t kFastSlotBytes = 65536 * 2;    // one u16 table
-constexpr size_t kFastGlobalMinBlocks = 1024;   // below this the LDS-table kernel is used
+constexpr size_t kFastGlobalMinBlocks = 257;    // up to one block per CU the LDS-table kernel is used
 constexpr size_t kHcSlots = 4096;               // resident workgroups of the HC kernel
 constexpr size_t kHcSlotBytes = 2 * 65536 * 4;  // hashTable + chainTable
 constexpr uint32_t kLegacyBlock = 8u << 20;      // blocks.go:11, frame.go:49
@@ -82,6 +82,13 @@ uint32_t host_xxh32_short(const uint8_t *p, size_t n) {  // n < 16
 int fast_generation() {
     const char *e = getenv("LZ4HIP_FAST");
     return (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 3;
+}
+// Block count from which the global-table kernel is used (LZ4HIP_FAST_GLOBAL_MIN
+// overrides it for sweeps).
+size_t fast_global_min_blocks() {
+    const char *e = getenv("LZ4HIP_FAST_GLOBAL_MIN");
+    if (e && *e) return (size_t)strtoull(e, nullptr, 10);
+    return kFastGlobalMinBlocks;
 }
 hipError_t launch_fast_any(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
                            uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,
@@ -134,7 +141,7 @@ int lz4hip_device_count(void) {
 size_t lz4hip_compress_bound(size_t n) { return n + n / 255 + 16; }
 
 size_t lz4hip_fast_workspace_bytes(size_t n_blocks) {
-    if (n_blocks < kFastGlobalMinBlocks) return 0;  // LDS-table kernel, no workspace needed
+    if (n_blocks < fast_global_min_blocks()) return 0;  // LDS-table kernel, no workspace needed
     if (fast_generation() == 4) return n_blocks * kFastSlotBytes;
     const size_t want = 4096;  // 16 waves per CU on 256 CUs
     return (n_blocks < want ? n_blocks : want) * kFastSlotBytes;
@@ -160,7 +167,7 @@ int lz4hip_compress_fast_blocks(const void *d_src, size_t n, uint32_t block_size
         return fail(LZ4HIP_ERR_ARG, "workspace unaligned or smaller than one table");
     // Few blocks: one block per CU with the table in LDS finishes each block sooner.
     // Many blocks: global tables and many waves per CU give the higher throughput.
-    if (nb < kFastGlobalMinBlocks) slots = 0;
+    if (nb < fast_global_min_blocks()) slots = 0;
     if (fast_generation() == 4 && d_workspace && workspace_bytes / kFastSlotBytes >= nb && slots) {
         HIPCHK(launch_fast4((const uint8_t *)d_src, n, block_size, nb, dst_mode, 0, (uint8_t *)d_dst,
                             dst_stride, d_result, (uint16_t *)d_workspace, (hipStream_t)stream));

@@ -191,7 +191,7 @@ def test_xxh32_stream_update_chain(T, oracle):
 
 
 def test_fast_many_blocks_global_table_kernel(T, oracle):
-    """>= 1024 blocks selects the global-table kernel (many waves per CU); its bytes
+    """>= 257 blocks select the global-table kernel (many waves per CU); its bytes
     must equal the LDS-table kernel's and the oracle's."""
     from lz4_amd import corpus, device as dev
     bs = 1 << 16
