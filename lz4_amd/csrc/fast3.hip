@@ -24,6 +24,9 @@
 
 namespace lz4hip {
 
+constexpr int kSrcBuf = 2048;   // LDS bytes of buffered source per wave
+constexpr int kSrcReach = 84;   // phase A reads s[wbase-8, wbase+84)
+
 // Lane `l` of `old` takes the wave-uniform value `v` (v_cmp + v_cndmask: the VOP3
 // form of v_writelane_b32 cannot take two SGPR operands on gfx9).
 #define wrlane(old, v, l) ((lane == (l)) ? (v) : (old))
@@ -71,7 +74,8 @@ __device__ __forceinline__ int len_tail_size(int len) {  // bytes after the toke
 template <bool kGlobal, typename TablePtr>
 __device__ __forceinline__ int fast3_block(const uint8_t *__restrict__ s, const int n,
                                            uint8_t *__restrict__ d, const int dlen,
-                                           TablePtr table, uint32_t *tag, const int lane) {
+                                           TablePtr table, uint32_t *tag, uint8_t *sbuf,
+                                           const int lane) {
     const int bound = (int)compress_bound32((uint32_t)n);
     const bool not_compressible = dlen < bound;  // block.go:110
     {  // reset(): block.go:94,107 -- an all-zero table is the cleared-bitmap state
@@ -85,17 +89,40 @@ __device__ __forceinline__ int fast3_block(const uint8_t *__restrict__ s, const 
     int si = 0, di = 0, anchor = 0;
     const int sn = n - kMfLimit;
     bool failed = false, finished = false, pending = false;
+    // The window's own source bytes -- s[wbase-8, wbase+84) -- are read through an
+    // LDS buffer holding s[sb, se), refilled with one coalesced load every ~40
+    // windows: the sequential part of the input costs no global round trip per window.
+    int sb = 0, se = 0;
 
     while (si < sn && !failed && !finished) {
         si = (int)rfl((uint32_t)si);
         di = (int)rfl((uint32_t)di);
         anchor = (int)rfl((uint32_t)anchor);
+        sb = (int)rfl((uint32_t)sb);
+        se = (int)rfl((uint32_t)se);
         // ================= Phase A: lane l <-> position wbase + l =================
         const int wbase = si - 2;  // lane 0 is the position of a pending put(si-2)
+        if (wbase + kSrcReach > se && se < n) {
+            sb = wbase - 8 < 0 ? 0 : (wbase - 8) & ~15;
+            const int cnt = n - sb < kSrcBuf ? n - sb : kSrcBuf;
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int k = lane * 16; k < cnt; k += kWave * 16) {
+                if (k + 16 <= cnt) {
+                    const uint64_t a = ld64(s + sb + k), b = ld64(s + sb + k + 8);
+                    *(uint64_t *)(sbuf + k) = a;
+                    *(uint64_t *)(sbuf + k + 8) = b;
+                } else {
+                    for (int j = k; j < cnt; j++) sbuf[j] = s[sb + j];
+                }
+            }
+            se = sb + cnt;
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        const uint8_t *sl = sbuf - sb;  // sl[q] == s[q] for sb <= q < se
         const int p = wbase + lane;
         const bool valid = p >= 0 && p <= sn + 1;
         uint64_t x = 0;
-        if (valid) x = ld64(s + p);
+        if (valid) __builtin_memcpy(&x, sl + p, 8);
         const uint32_t h = hash6(x);
         uint32_t tv = 0;
         if (valid) tv = tab_load<kGlobal>(table, h);
@@ -120,15 +147,15 @@ __device__ __forceinline__ int fast3_block(const uint8_t *__restrict__ s, const 
         if (offok) cw = ld32(s + ref);
         if (f0ok) {
             r0 = ld64(s + ref + 4);
-            q0 = ld64(s + p + 4);
+            __builtin_memcpy(&q0, sl + p + 4, 8);
         }
         if (f1ok) {
             r1 = ld64(s + ref + 12);
-            q1 = ld64(s + p + 12);
+            __builtin_memcpy(&q1, sl + p + 12, 8);
         }
         if (bok) {
             rb = ld64(s + ref - 8);
-            qb = ld64(s + p - 8);
+            __builtin_memcpy(&qb, sl + p - 8, 8);
         }
         const bool m4 = offok && cw == (uint32_t)x;
         int mendv = p + kMinMatch;  // end of the match that starts at p (absolute)
@@ -371,13 +398,14 @@ __global__ __launch_bounds__(64) void k_fast3_lds(const uint8_t *__restrict__ sr
                                                   int32_t *__restrict__ result) {
     __shared__ uint16_t table[1 << 16];
     __shared__ uint32_t tag[kTagN];
+    __shared__ __attribute__((aligned(16))) uint8_t sbuf[kSrcBuf];
     const int lane = lane_id();
     const size_t b = blockIdx.x;
     const size_t start = b * (size_t)block_size;
     const size_t left = n_total > start ? n_total - start : 0;
     const int n = (int)(left < block_size ? left : block_size);
     const int r = fast3_block<false>(src + start, n, dst + b * dst_stride,
-                                     block_dlen2(dst_mode, n, dst_len_x), table, tag, lane);
+                                     block_dlen2(dst_mode, n, dst_len_x), table, tag, sbuf, lane);
     if (lane == 0) result[b] = r;
 }
 
@@ -389,6 +417,7 @@ __global__ __launch_bounds__(64) void k_fast3_gtab(const uint8_t *__restrict__ s
                                                    int32_t *__restrict__ result,
                                                    uint16_t *__restrict__ ws) {
     __shared__ uint32_t tag[kTagN];
+    __shared__ __attribute__((aligned(16))) uint8_t sbuf[kSrcBuf];
     const int lane = lane_id();
     uint16_t *table = ws + (size_t)blockIdx.x * (1 << 16);
     for (size_t b = blockIdx.x; b < nb; b += gridDim.x) {
@@ -396,7 +425,7 @@ __global__ __launch_bounds__(64) void k_fast3_gtab(const uint8_t *__restrict__ s
         const size_t left = n_total > start ? n_total - start : 0;
         const int n = (int)(left < block_size ? left : block_size);
         const int r = fast3_block<true>(src + start, n, dst + b * dst_stride,
-                                        block_dlen2(dst_mode, n, dst_len_x), table, tag, lane);
+                                        block_dlen2(dst_mode, n, dst_len_x), table, tag, sbuf, lane);
         if (lane == 0) result[b] = r;
         __syncthreads();
     }
