@@ -64,6 +64,9 @@ extern "C" {
  * only, 8 MiB blocks each compressed into an 8 MiB dst (lz4stream/block.go:226-227),
  * no end mark, no content checksum; block_size and content_size are ignored. */
 #define LZ4HIP_F_LEGACY 16u
+/* Reported by lz4hip_frame_parse_header only: FLG bit 5 clear, blocks depend on the
+ * previous 64 KiB of output (reader.go:86-90,176-189). */
+#define LZ4HIP_F_LINKED 32u
 
 const char *lz4hip_last_error(void);          /* thread-local text of the last failure */
 int lz4hip_device_count(void);                /* GPUs visible; 0 if none */
@@ -155,6 +158,15 @@ int lz4hip_frame_scatter(const void *d_src, size_t n, uint32_t block_size, const
 size_t lz4hip_frame_header(uint8_t *h_dst16, uint32_t block_size, uint32_t flags,
                            uint64_t content_size);
 size_t lz4hip_frame_trailer(uint8_t *h_dst8, uint32_t flags, uint32_t content_xxh);
+/* Frame.ParseHeaders + FrameDescriptor.initR (internal/lz4stream/frame.go:80-111,169-200),
+ * host only: skips skippable frames, accepts the standard and the legacy magic, checks
+ * the descriptor checksum and the block-size index.  On LZ4HIP_OK: *block_size (8 MiB for
+ * legacy), *flags (LZ4HIP_F_BLOCK_CHECKSUM | _CONTENT_CHECKSUM | _CONTENT_SIZE | _LEGACY |
+ * _LINKED), *content_size, *header_len = offset of the first block.  Errors:
+ * LZ4HIP_ERR_FRAME (bad magic), _HEADER_CHECKSUM, _BLOCK_SIZE, _SHORT (input ends inside
+ * the header: Go's io.ErrUnexpectedEOF).  Any out pointer may be NULL. */
+int lz4hip_frame_parse_header(const uint8_t *src, size_t n, uint32_t *block_size, uint32_t *flags,
+                              uint64_t *content_size, size_t *header_len);
 /* Upper bound of a frame of n source bytes. */
 size_t lz4hip_frame_bound(size_t n, uint32_t block_size, uint32_t flags);
 

@@ -15,7 +15,7 @@ OK, ERR_ARG, ERR_HIP, ERR_SHORT, ERR_FRAME = 0, -1, -2, -3, -4
 ERR_HEADER_CHECKSUM, ERR_BLOCK_SIZE, ERR_BLOCK_CHECKSUM, ERR_FRAME_CHECKSUM, ERR_BLOCK = -5, -6, -7, -8, -9
 
 DST_FRAME, DST_BOUND = 0, 1
-F_BLOCK_CHECKSUM, F_CONTENT_CHECKSUM, F_CONTENT_SIZE, F_READFROM, F_LEGACY = 1, 2, 4, 8, 16
+F_BLOCK_CHECKSUM, F_CONTENT_CHECKSUM, F_CONTENT_SIZE, F_READFROM, F_LEGACY, F_LINKED = 1, 2, 4, 8, 16, 32
 
 # every symbol include/lz4hip.h declares: (restype, argtypes)
 _vp, _sz, _u32, _u64, _i64, _int = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int64, C.c_int
@@ -36,6 +36,7 @@ SYMBOLS = {
     "lz4hip_frame_scatter": (_int, [_vp, _sz, _u32, _vp, _sz, _vp, _vp, _vp, _sz, _vp, _u64, _vp]),
     "lz4hip_frame_header": (_sz, [_vp, _u32, _u32, _u64]),
     "lz4hip_frame_trailer": (_sz, [_vp, _u32, _u32]),
+    "lz4hip_frame_parse_header": (_int, [_vp, _sz, _vp, _vp, _vp, _vp]),
     "lz4hip_frame_bound": (_sz, [_sz, _u32, _u32]),
     "lz4hip_compress_block": (_i64, [_vp, _sz, _vp, _sz]),
     "lz4hip_compress_block_hc": (_i64, [_vp, _sz, _vp, _sz, _u32]),

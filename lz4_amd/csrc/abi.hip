@@ -543,6 +543,65 @@ int64_t lz4hip_frame_compress(const uint8_t *src, size_t n, uint32_t block_size,
     return rc == LZ4HIP_OK ? total : rc;
 }
 
+int lz4hip_frame_parse_header(const uint8_t *src, size_t n, uint32_t *block_size, uint32_t *flags,
+                              uint64_t *content_size, size_t *header_len) {
+    if (n && !src) return fail(LZ4HIP_ERR_ARG, "null pointer");
+    size_t si = 0;
+    auto rd32 = [&](size_t at) {
+        uint32_t v;
+        memcpy(&v, src + at, 4);
+        return v;
+    };
+    uint32_t fl = 0, bs = 0;
+    uint64_t cs = 0;
+    for (;;) {  // frame.go:80-111
+        if (n - si < 4) return fail(LZ4HIP_ERR_SHORT, "unexpected EOF in the frame header");
+        const uint32_t magic = rd32(si);
+        si += 4;
+        if (magic == 0x184D2204u) break;
+        if (magic == 0x184C2102u) {  // frame.go:169-174
+            fl = LZ4HIP_F_LEGACY;
+            bs = kLegacyBlock;
+            break;
+        }
+        if (magic >> 8 == 0x184D2A50u >> 8) {  // skippable frame
+            if (n - si < 4) return fail(LZ4HIP_ERR_SHORT, "unexpected EOF in the frame header");
+            const uint32_t skip = rd32(si);
+            si += 4;
+            if (n - si < skip) return fail(LZ4HIP_ERR_SHORT, "unexpected EOF in a skippable frame");
+            si += skip;
+            continue;
+        }
+        return fail(LZ4HIP_ERR_FRAME, "invalid frame magic");
+    }
+    if (!(fl & LZ4HIP_F_LEGACY)) {  // frame.go:175-200
+        if (n - si < 3) return fail(LZ4HIP_ERR_SHORT, "unexpected EOF in the frame header");
+        const size_t d0 = si;
+        const uint16_t f = (uint16_t)(src[si] | (src[si + 1] << 8));
+        si += 2;
+        if (f >> 3 & 1) {
+            if (n - si < 9) return fail(LZ4HIP_ERR_SHORT, "unexpected EOF in the frame header");
+            memcpy(&cs, src + si, 8);
+            si += 8;
+            fl |= LZ4HIP_F_CONTENT_SIZE;
+        }
+        if ((uint8_t)(host_xxh32_short(src + d0, si - d0) >> 8) != src[si])
+            return fail(LZ4HIP_ERR_HEADER_CHECKSUM, "invalid header checksum");
+        si += 1;
+        const int idx = f >> 12 & 7;
+        if (idx < 4) return fail(LZ4HIP_ERR_BLOCK_SIZE, "invalid block size");
+        bs = 1u << (8 + 2 * idx);
+        if (f >> 4 & 1) fl |= LZ4HIP_F_BLOCK_CHECKSUM;
+        if (f >> 2 & 1) fl |= LZ4HIP_F_CONTENT_CHECKSUM;
+        if (!(f >> 5 & 1)) fl |= LZ4HIP_F_LINKED;
+    }
+    if (block_size) *block_size = bs;
+    if (flags) *flags = fl;
+    if (content_size) *content_size = cs;
+    if (header_len) *header_len = si;
+    return LZ4HIP_OK;
+}
+
 // Legacy frame (magic 0x184C2102, frame.go:20,46-51,169-174): 8 MiB independent
 // blocks, no checksums, no end mark.  block.Read's legacy rules
 // (lz4stream/block.go:284-294): a size word equal to the magic starts a
@@ -629,37 +688,15 @@ int64_t lz4hip_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size
         return v;
     };
     // ---- headers: frame.go:80-111,169-200 (host; a few bytes) ----
-    for (;;) {
-        if (n - si < 4) return fail(LZ4HIP_ERR_FRAME, "truncated frame");
-        const uint32_t magic = rd32(si);
-        si += 4;
-        if (magic == 0x184D2204u) break;
-        if (magic >> 8 == 0x184D2A50u >> 8) {  // skippable frame
-            if (n - si < 4) return fail(LZ4HIP_ERR_FRAME, "truncated frame");
-            const uint32_t skip = rd32(si);
-            si += 4;
-            if (n - si < skip) return fail(LZ4HIP_ERR_FRAME, "truncated frame");
-            si += skip;
-            continue;
-        }
-        if (magic == 0x184C2102u) return legacy_uncompress(src, n, si, dst, dst_cap);
-        return fail(LZ4HIP_ERR_FRAME, "invalid frame magic");
+    uint32_t bs = 0, hflags = 0;
+    {
+        const int rc = lz4hip_frame_parse_header(src, n, &bs, &hflags, nullptr, &si);
+        if (rc == LZ4HIP_ERR_SHORT) return fail(LZ4HIP_ERR_FRAME, "truncated frame");
+        if (rc != LZ4HIP_OK) return rc;
     }
-    if (n - si < 3) return fail(LZ4HIP_ERR_FRAME, "truncated frame");
-    const size_t d0 = si;
-    const uint16_t f = (uint16_t)(src[si] | (src[si + 1] << 8));
-    si += 2;
-    if (f >> 3 & 1) {
-        if (n - si < 9) return fail(LZ4HIP_ERR_FRAME, "truncated frame");
-        si += 8;
-    }
-    if ((uint8_t)(host_xxh32_short(src + d0, si - d0) >> 8) != src[si])
-        return fail(LZ4HIP_ERR_HEADER_CHECKSUM, "invalid header checksum");
-    si += 1;
-    const int idx = f >> 12 & 7;
-    if (idx < 4) return fail(LZ4HIP_ERR_BLOCK_SIZE, "invalid block size");
-    const uint32_t bs = 1u << (8 + 2 * idx);
-    const bool bsum = f >> 4 & 1, csum = f >> 2 & 1, independent = f >> 5 & 1;
+    if (hflags & LZ4HIP_F_LEGACY) return legacy_uncompress(src, n, si, dst, dst_cap);
+    const bool bsum = hflags & LZ4HIP_F_BLOCK_CHECKSUM, csum = hflags & LZ4HIP_F_CONTENT_CHECKSUM,
+               independent = !(hflags & LZ4HIP_F_LINKED);
 
     // ---- block index: lz4stream/block.go:279-317 (host walk over size words) ----
     std::vector<uint64_t> off;
