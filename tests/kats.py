@@ -179,7 +179,7 @@ LONG_FRAMES = {
 }
 
 
-def emit_seq(lit, offset=0, mlen=0):
+def _seq(lit, offset=0, mlen=0):
     """One LZ4 sequence (decode_test.go emitSeq): literals then, when mlen >= 4, a match."""
     out = bytearray()
     ll = len(lit)
@@ -218,19 +218,19 @@ def linked_frames(xxh32):
         return out
 
     a = bytes(range(97, 123)) * 3                       # 78 bytes of history
-    b1 = emit_seq(a)
+    b1 = _seq(a)
     # block 2: 5 literals, then 20 bytes from 30 bytes back (all inside block 1)
-    b2 = emit_seq(b"HELLO", 30 + 5, 20) + emit_seq(b"tail!")
+    b2 = _seq(b"HELLO", 30 + 5, 20) + _seq(b"tail!")
     d2 = b"HELLO" + a[-30:-10] + b"tail!"
     # block 3: match that starts in the history and runs over its own output (overlap)
-    b3 = emit_seq(b"", 3, 40) + emit_seq(b"end..")
+    b3 = _seq(b"", 3, 40) + _seq(b"end..")
     h3 = a + d2
     d3 = bytearray()
     for k in range(40):
         d3.append((h3 + bytes(d3))[len(h3) + k - 3])
     d3 = bytes(d3) + b"end.."
     raw4 = b"RAWBLOCK" * 4
-    b5 = emit_seq(b"", len(raw4), 12) + emit_seq(b"12345")
+    b5 = _seq(b"", len(raw4), 12) + _seq(b"12345")
     d5 = raw4[:12] + b"12345"
     blocks = [(b1, False, a), (b2, False, d2), (b3, False, d3)]
     full = a + d2 + d3
@@ -241,16 +241,16 @@ def linked_frames(xxh32):
          frame(blocks + [(raw4, True, raw4), (b5, False, d5)], bsum=True, csum=True,
                expect=full + raw4 + d5), full + raw4 + d5),
         ("bad_content_checksum", frame(blocks, csum=True, expect=full, bad_cs=True), None),
-        ("offset_before_history", frame([(b1, False, a), (emit_seq(b"x", 80, 4) + emit_seq(b"yyyyy"), False, b"")]), None),
-        ("first_block_needs_history", frame([(emit_seq(b"ab", 3, 4) + emit_seq(b"yyyyy"), False, b"")]), None),
+        ("offset_before_history", frame([(b1, False, a), (_seq(b"x", 80, 4) + _seq(b"yyyyy"), False, b"")]), None),
+        ("first_block_needs_history", frame([(_seq(b"ab", 3, 4) + _seq(b"yyyyy"), False, b"")]), None),
     ]
     # far history: 70,000 bytes of filler, then a match 65,535 back
     filler1 = bytes((i * 7 + 3) & 0xFF for i in range(60000))
     filler2 = bytes((i * 13 + 5) & 0xFF for i in range(10000))
-    far = emit_seq(b"Z", 65535, 8) + emit_seq(b"done.")
+    far = _seq(b"Z", 65535, 8) + _seq(b"done.")
     hist = filler1 + filler2 + b"Z"
     dfar = b"Z" + hist[len(hist) - 65535:len(hist) - 65535 + 8] + b"done."
-    out.append(("offset_65535", frame([(emit_seq(filler1), False, filler1), (emit_seq(filler2), False, filler2),
+    out.append(("offset_65535", frame([(_seq(filler1), False, filler1), (_seq(filler2), False, filler2),
                                        (far, False, dfar)], csum=True, expect=filler1 + filler2 + dfar),
                 filler1 + filler2 + dfar))
     return out
