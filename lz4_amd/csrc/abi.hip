@@ -115,12 +115,26 @@ hipError_t launch_decode_any(const uint8_t *src, const uint64_t *off, const uint
     }
 }
 
-// RAII device buffer for the host-pointer entry points.
+// The host-pointer entry points run on the calling thread's own stream
+// (hipStreamPerThread), never on the legacy null stream: calls made from several OS
+// threads (cgo runs each goroutine's call on its own thread) then overlap on the GPU
+// instead of queueing behind each other.  hcopy = a blocking copy on that stream.
+const hipStream_t kHostStream = hipStreamPerThread;
+hipError_t hcopy(void *dst, const void *src, size_t n, hipMemcpyKind kind) {
+    hipError_t e = hipMemcpyAsync(dst, src, n, kind, kHostStream);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(kHostStream);
+}
+
+// RAII device buffer for the host-pointer entry points: stream-ordered allocation on the
+// calling thread's stream.  hipMalloc/hipFree would do, but hipFree waits for EVERY stream
+// of the device, which serialises concurrent callers behind each other's kernels.
+// Every use of the buffer on another stream is synchronised before the owner returns.
 struct DevBuf {
     void *p = nullptr;
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+    hipError_t alloc(size_t n) { return hipMallocAsync(&p, n ? n : 16, kHostStream); }
     ~DevBuf() {
-        if (p) (void)hipFree(p);
+        if (p) (void)hipFreeAsync(p, kHostStream);
     }
     template <class T> T *as() { return static_cast<T *>(p); }
 };
@@ -323,21 +337,21 @@ static int64_t compress_one(const uint8_t *src, size_t n, uint8_t *dst, size_t d
     HIPCHK(d_src.alloc(n + 16));
     HIPCHK(d_dst.alloc(dst_len + 16));
     HIPCHK(d_res.alloc(sizeof(int32_t)));
-    if (n) HIPCHK(hipMemcpy(d_src.p, src, n, hipMemcpyHostToDevice));
+    if (n) HIPCHK(hcopy(d_src.p, src, n, hipMemcpyHostToDevice));
     // one block that spans the whole input: cut size = max(n, 1)
     const uint32_t bs = (uint32_t)(n ? n : 1);
     if (hc) {
         HIPCHK(d_ws.alloc(kHcSlotBytes));
         HIPCHK(launch_hc(d_src.as<uint8_t>(), n, bs, 1, depth, kDstExplicit, (uint32_t)dst_len,
                          d_dst.as<uint8_t>(), 0, d_res.as<int32_t>(), d_ws.as<uint32_t>(), 1,
-                         nullptr));
+                         kHostStream));
     } else {
         HIPCHK(launch_fast_any(d_src.as<uint8_t>(), n, bs, 1, kDstExplicit, (uint32_t)dst_len,
-                           d_dst.as<uint8_t>(), 0, d_res.as<int32_t>(), nullptr, 0, nullptr));
+                           d_dst.as<uint8_t>(), 0, d_res.as<int32_t>(), nullptr, 0, kHostStream));
     }
     int32_t r = 0;
-    HIPCHK(hipMemcpy(&r, d_res.p, sizeof r, hipMemcpyDeviceToHost));
-    if (r > 0) HIPCHK(hipMemcpy(dst, d_dst.p, (size_t)r, hipMemcpyDeviceToHost));
+    HIPCHK(hcopy(&r, d_res.p, sizeof r, hipMemcpyDeviceToHost));
+    if (r > 0) HIPCHK(hcopy(dst, d_dst.p, (size_t)r, hipMemcpyDeviceToHost));
     return r;  // n, 0 or -1: the Go conventions of lz4.go:59-69
 }
 
@@ -368,21 +382,21 @@ static int64_t uncompress_one(const uint8_t *src, size_t n, uint8_t *dst, size_t
     HIPCHK(d_src.alloc(n));
     HIPCHK(d_out.alloc(dict_len + dst_len));  // [dictionary | dst]
     HIPCHK(d_meta.alloc(32));
-    HIPCHK(hipMemcpy(d_src.p, src, n, hipMemcpyHostToDevice));
-    if (dict_len) HIPCHK(hipMemcpy(d_out.p, dict, dict_len, hipMemcpyHostToDevice));
+    HIPCHK(hcopy(d_src.p, src, n, hipMemcpyHostToDevice));
+    if (dict_len) HIPCHK(hcopy(d_out.p, dict, dict_len, hipMemcpyHostToDevice));
     struct {
         uint64_t off;
         uint32_t sw;
         int32_t out;
     } meta = {0, (uint32_t)n, 0};
-    HIPCHK(hipMemcpy(d_meta.p, &meta, sizeof meta, hipMemcpyHostToDevice));
+    HIPCHK(hcopy(d_meta.p, &meta, sizeof meta, hipMemcpyHostToDevice));
     uint8_t *m = d_meta.as<uint8_t>();
     HIPCHK(launch_decode_any(d_src.as<uint8_t>(), (const uint64_t *)m, (const uint32_t *)(m + 8), 1,
                          d_out.as<uint8_t>() + dict_len, 0, (uint32_t)dst_len,
-                         (uint32_t)dict_len, (int32_t *)(m + 12), nullptr));
-    HIPCHK(hipMemcpy(&meta, d_meta.p, sizeof meta, hipMemcpyDeviceToHost));
+                         (uint32_t)dict_len, (int32_t *)(m + 12), kHostStream));
+    HIPCHK(hcopy(&meta, d_meta.p, sizeof meta, hipMemcpyDeviceToHost));
     if (meta.out > 0)
-        HIPCHK(hipMemcpy(dst, d_out.as<uint8_t>() + dict_len, (size_t)meta.out,
+        HIPCHK(hcopy(dst, d_out.as<uint8_t>() + dict_len, (size_t)meta.out,
                          hipMemcpyDeviceToHost));
     return meta.out;
 }
@@ -399,7 +413,7 @@ uint32_t lz4hip_xxh32(const uint8_t *p, size_t n) {
         g_err = "hipMalloc failed";
         return 0;
     }
-    if (n && hipMemcpy(d_src.p, p, n, hipMemcpyHostToDevice) != hipSuccess) {
+    if (n && hcopy(d_src.p, p, n, hipMemcpyHostToDevice) != hipSuccess) {
         g_err = "hipMemcpy failed";
         return 0;
     }
@@ -408,13 +422,13 @@ uint32_t lz4hip_xxh32(const uint8_t *p, size_t n) {
     if (n <= 0x7fffffffu) {
         DevBuf d_len;
         if (d_len.alloc(4) != hipSuccess) return 0;
-        (void)hipMemcpy(d_len.p, &len, 4, hipMemcpyHostToDevice);
+        (void)hcopy(d_len.p, &len, 4, hipMemcpyHostToDevice);
         (void)launch_xxh32_blocks(d_src.as<uint8_t>(), n, n ? n : 1, nullptr, d_len.as<int32_t>(),
-                                  1, d_out.as<uint32_t>(), nullptr);
-        (void)hipMemcpy(&out, d_out.p, 4, hipMemcpyDeviceToHost);
+                                  1, d_out.as<uint32_t>(), kHostStream);
+        (void)hcopy(&out, d_out.p, 4, hipMemcpyDeviceToHost);
     } else {
-        (void)launch_xxh32_stream(d_src.as<uint8_t>(), n, d_out.as<uint32_t>(), nullptr);
-        (void)hipMemcpy(&out, d_out.p, 4, hipMemcpyDeviceToHost);
+        (void)launch_xxh32_stream(d_src.as<uint8_t>(), n, d_out.as<uint32_t>(), kHostStream);
+        (void)hcopy(&out, d_out.p, 4, hipMemcpyDeviceToHost);
     }
     return out;
 }
@@ -460,8 +474,9 @@ int64_t lz4hip_frame_compress(const uint8_t *src, size_t n, uint32_t block_size,
     HIPCHK(d_off.alloc((nb + 1) * sizeof(uint64_t)));
     HIPCHK(d_frame.alloc(dst_cap));
     HIPCHK(d_cs.alloc(4));
-    HIPCHK(hipStreamCreate(&s_main));
-    HIPCHK(hipStreamCreate(&s_sum));
+    HIPCHK(hipStreamSynchronize(kHostStream));  // the allocations above are ordered on it
+    HIPCHK(hipStreamCreateWithFlags(&s_main, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&s_sum, hipStreamNonBlocking));
     int rc = LZ4HIP_OK;
     int64_t total = 0;
     do {
@@ -473,7 +488,7 @@ int64_t lz4hip_frame_compress(const uint8_t *src, size_t n, uint32_t block_size,
             break;                        \
         }                                 \
     }
-        if (n) STEP(hipMemcpy(d_src.p, src, n, hipMemcpyHostToDevice));
+        if (n) STEP(hcopy(d_src.p, src, n, hipMemcpyHostToDevice));
         STEP(hipMemsetAsync(d_res.p, 0, (nb + 1) * sizeof(int32_t), s_main));
         // content checksum: serial walk, overlapped on its own stream
         if (csum) STEP(launch_xxh32_stream(d_src.as<uint8_t>(), n, d_cs.as<uint32_t>(), s_sum));
@@ -509,7 +524,7 @@ int64_t lz4hip_frame_compress(const uint8_t *src, size_t n, uint32_t block_size,
         STEP(hipStreamSynchronize(s_main));
         STEP(hipStreamSynchronize(s_sum));
         uint32_t cs = 0;
-        if (csum) STEP(hipMemcpy(&cs, d_cs.p, 4, hipMemcpyDeviceToHost));
+        if (csum) STEP(hcopy(&cs, d_cs.p, 4, hipMemcpyDeviceToHost));
         size_t tlen;
         if (legacy) {  // no end mark (frame.go:63-65); ReadFrom's empty block: size 1, token 00
             tlen = 0;
@@ -532,7 +547,7 @@ int64_t lz4hip_frame_compress(const uint8_t *src, size_t n, uint32_t block_size,
         }
         memcpy(dst, hdr, hlen);
         if (end_off > hlen)
-            STEP(hipMemcpy(dst + hlen, d_frame.as<uint8_t>() + hlen, end_off - hlen,
+            STEP(hcopy(dst + hlen, d_frame.as<uint8_t>() + hlen, end_off - hlen,
                            hipMemcpyDeviceToHost));
         memcpy(dst + end_off, trl, tlen);
         total = (int64_t)(end_off + tlen);
@@ -656,12 +671,12 @@ static int64_t legacy_uncompress(const uint8_t *src, size_t n, size_t si, uint8_
         HIPCHK(d_sw.alloc(nb * 4));
         HIPCHK(d_out.alloc(nb * (size_t)cap));
         HIPCHK(d_len.alloc(nb * 4));
-        HIPCHK(hipMemcpy(d_src.p, src, n, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(d_off.p, off.data(), nb * 8, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(d_sw.p, sw.data(), nb * 4, hipMemcpyHostToDevice));
+        HIPCHK(hcopy(d_src.p, src, n, hipMemcpyHostToDevice));
+        HIPCHK(hcopy(d_off.p, off.data(), nb * 8, hipMemcpyHostToDevice));
+        HIPCHK(hcopy(d_sw.p, sw.data(), nb * 4, hipMemcpyHostToDevice));
         HIPCHK(launch_decode_any(d_src.as<uint8_t>(), d_off.as<uint64_t>(), d_sw.as<uint32_t>(), nb,
-                                 d_out.as<uint8_t>(), cap, cap, 0, d_len.as<int32_t>(), nullptr));
-        HIPCHK(hipMemcpy(len.data(), d_len.p, nb * 4, hipMemcpyDeviceToHost));
+                                 d_out.as<uint8_t>(), cap, cap, 0, d_len.as<int32_t>(), kHostStream));
+        HIPCHK(hcopy(len.data(), d_len.p, nb * 4, hipMemcpyDeviceToHost));
     }
     size_t total = 0;
     for (size_t b = 0; b < cand.size(); b++) {
@@ -672,7 +687,7 @@ static int64_t legacy_uncompress(const uint8_t *src, size_t n, size_t si, uint8_
         if (len[b] < 0) return fail(LZ4HIP_ERR_BLOCK, "invalid source or destination buffer too short");
         if (total + (size_t)len[b] > dst_cap) return fail(LZ4HIP_ERR_SHORT, "dst_cap too small");
         if (len[b])
-            HIPCHK(hipMemcpy(dst + total, d_out.as<uint8_t>() + b * (size_t)cap, (size_t)len[b],
+            HIPCHK(hcopy(dst + total, d_out.as<uint8_t>() + b * (size_t)cap, (size_t)len[b],
                              hipMemcpyDeviceToHost));
         total += (size_t)len[b];
     }
@@ -738,27 +753,27 @@ int64_t lz4hip_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size
     HIPCHK(d_len.alloc(nb * 4));
     HIPCHK(d_xxh.alloc(nb * 4));
     HIPCHK(d_cs.alloc(4));
-    HIPCHK(hipMemcpy(d_src.p, src, n, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_off.p, off.data(), nb * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_sw.p, sw.data(), nb * 4, hipMemcpyHostToDevice));
+    HIPCHK(hcopy(d_src.p, src, n, hipMemcpyHostToDevice));
+    HIPCHK(hcopy(d_off.p, off.data(), nb * 8, hipMemcpyHostToDevice));
+    HIPCHK(hcopy(d_sw.p, sw.data(), nb * 4, hipMemcpyHostToDevice));
     DevBuf d_ooff;  // linked frames: where each block's output starts in d_out
     if (independent) {
         HIPCHK(launch_decode_any(d_src.as<uint8_t>(), d_off.as<uint64_t>(), d_sw.as<uint32_t>(), nb,
-                                 d_out.as<uint8_t>(), bs, bs, 0, d_len.as<int32_t>(), nullptr));
+                                 d_out.as<uint8_t>(), bs, bs, 0, d_len.as<int32_t>(), kHostStream));
     } else {  // reader.go:86-90,176-189: dependent blocks decode in order, output packed
         HIPCHK(d_ooff.alloc(nb * 8));
         HIPCHK(launch_decode2_linked(d_src.as<uint8_t>(), d_off.as<uint64_t>(), d_sw.as<uint32_t>(),
                                      nb, d_out.as<uint8_t>(), bs, d_len.as<int32_t>(),
-                                     d_ooff.as<uint64_t>(), nullptr));
+                                     d_ooff.as<uint64_t>(), kHostStream));
     }
     if (bsum)  // verified on the DECODED bytes: lz4stream/block.go:330-335
         HIPCHK(launch_xxh32_blocks(d_out.as<uint8_t>(), nb * (size_t)bs, bs,
                                    independent ? nullptr : d_ooff.as<uint64_t>(),
-                                   d_len.as<int32_t>(), nb, d_xxh.as<uint32_t>(), nullptr));
+                                   d_len.as<int32_t>(), nb, d_xxh.as<uint32_t>(), kHostStream));
     std::vector<int32_t> len(nb);
     std::vector<uint32_t> got(nb);
-    HIPCHK(hipMemcpy(len.data(), d_len.p, nb * 4, hipMemcpyDeviceToHost));
-    if (bsum) HIPCHK(hipMemcpy(got.data(), d_xxh.p, nb * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hcopy(len.data(), d_len.p, nb * 4, hipMemcpyDeviceToHost));
+    if (bsum) HIPCHK(hcopy(got.data(), d_xxh.p, nb * 4, hipMemcpyDeviceToHost));
     // first failing block wins, in stream order (lz4stream/block.go:187-194)
     size_t total = 0;
     bool dense = true;  // every block but the last is full (or packed): one contiguous copy
@@ -770,12 +785,12 @@ int64_t lz4hip_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size
     }
     if (total > dst_cap) return fail(LZ4HIP_ERR_SHORT, "dst_cap too small");
     if (dense) {
-        HIPCHK(hipMemcpy(dst, d_out.p, total, hipMemcpyDeviceToHost));
+        HIPCHK(hcopy(dst, d_out.p, total, hipMemcpyDeviceToHost));
     } else {
         size_t at = 0;
         for (size_t b = 0; b < nb; b++) {
             if (len[b])
-                HIPCHK(hipMemcpy(dst + at, d_out.as<uint8_t>() + b * (size_t)bs, (size_t)len[b],
+                HIPCHK(hcopy(dst + at, d_out.as<uint8_t>() + b * (size_t)bs, (size_t)len[b],
                                  hipMemcpyDeviceToHost));
             at += (size_t)len[b];
         }
@@ -783,15 +798,15 @@ int64_t lz4hip_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size
     if (csum) {  // frame.go:117-131; serial walk over the decoded stream
         uint32_t cs = 0;
         if (dense) {
-            HIPCHK(launch_xxh32_stream(d_out.as<uint8_t>(), total, d_cs.as<uint32_t>(), nullptr));
+            HIPCHK(launch_xxh32_stream(d_out.as<uint8_t>(), total, d_cs.as<uint32_t>(), kHostStream));
         } else {
             DevBuf d_flat;
             HIPCHK(d_flat.alloc(total));
-            HIPCHK(hipMemcpy(d_flat.p, dst, total, hipMemcpyHostToDevice));
-            HIPCHK(launch_xxh32_stream(d_flat.as<uint8_t>(), total, d_cs.as<uint32_t>(), nullptr));
-            HIPCHK(hipDeviceSynchronize());
+            HIPCHK(hcopy(d_flat.p, dst, total, hipMemcpyHostToDevice));
+            HIPCHK(launch_xxh32_stream(d_flat.as<uint8_t>(), total, d_cs.as<uint32_t>(), kHostStream));
+            HIPCHK(hipStreamSynchronize(kHostStream));
         }
-        HIPCHK(hipMemcpy(&cs, d_cs.p, 4, hipMemcpyDeviceToHost));
+        HIPCHK(hcopy(&cs, d_cs.p, 4, hipMemcpyDeviceToHost));
         if (cs != want_cs) return fail(LZ4HIP_ERR_FRAME_CHECKSUM, "invalid frame checksum");
     }
     return (int64_t)total;
