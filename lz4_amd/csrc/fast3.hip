@@ -201,6 +201,9 @@ __device__ __forceinline__ int fast3_block(const uint8_t *__restrict__ s, const 
         uint64_t P = pending ? 1ull : 0ull;  // lanes put() since the snapshot; lane 0 = put(si-2)
         pending = false;
 
+        // The next window will gather the table for positions wbase+64.. (unless a long
+        // match jumps over them): touch those lines now, so that the walk below hides
+        // their trip from HBM and the next gather finds them in L2.
         // ================= Phase B: where are the matches =================
         for (;;) {
             si = (int)rfl((uint32_t)si);
@@ -336,7 +339,11 @@ __device__ __forceinline__ int fast3_block(const uint8_t *__restrict__ s, const 
                     uint8_t *o = d + di + (incl - esz);
                     *o++ = (uint8_t)((m_len < 0xF ? m_len : 0xF) | ((l_len < 0xF ? l_len : 0xF) << 4));
                     if (l_len >= 0xF) o += lane_len_tail(o, l_len - 0xF);
-                    lane_copy_exact(o, s + anch, l_len);
+                    // literals are the bytes just before the match: usually still in sbuf
+                    if (anch >= sb)
+                        lane_copy_exact(o, sl + anch, l_len);
+                    else
+                        lane_copy_exact(o, s + anch, l_len);
                     o += l_len;
                     const int ofs = offv;
                     o[0] = (uint8_t)ofs;
@@ -425,7 +432,8 @@ __global__ __launch_bounds__(64) void k_fast3_gtab(const uint8_t *__restrict__ s
         const size_t left = n_total > start ? n_total - start : 0;
         const int n = (int)(left < block_size ? left : block_size);
         const int r = fast3_block<true>(src + start, n, dst + b * dst_stride,
-                                        block_dlen2(dst_mode, n, dst_len_x), table, tag, sbuf, lane);
+                                                   block_dlen2(dst_mode, n, dst_len_x), table, tag,
+                                                   sbuf, lane);
         if (lane == 0) result[b] = r;
         __syncthreads();
     }
