@@ -31,7 +31,8 @@ sys.path.insert(0, ROOT)
 from lz4_amd import _lib, corpus, device as dev  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-RANDOM_RW_PEAK_GREQ = 40.3  # profiles/r1_random_access_microbench.txt: rd+wr, 8 GiB footprint
+RANDOM_RW_PEAK_GREQ = 49.9  # profiles/r1_random_access_microbench.txt: random reads, 8 GiB footprint
+# (read+write pairs: 40.3, writes alone: 22.1 -- reads are the upper bound of any mix)
 
 
 def parse():
@@ -207,7 +208,8 @@ def main():
             req = (tj["read_requests_per_byte"] + tj["write_requests_per_byte"]) * n
             ra = {"achieved_Greq_s": round(req / t_comp / 1e9, 2), "peak_Greq_s": RANDOM_RW_PEAK_GREQ,
                   "frac": round(req / t_comp / 1e9 / RANDOM_RW_PEAK_GREQ, 3),
-                  "note": "random 2-byte table get+put; peak = tools/micro/randacc.hip rd+wr at 8 GiB footprint"}
+                  "note": "fabric requests of the random 2-byte table/candidate accesses vs the measured "
+                          "random-read rate of the chip (tools/micro/randacc.hip, 8 GiB footprint)"}
         except (OSError, KeyError, ValueError):
             pass
         line = {

@@ -1,8 +1,8 @@
 import sys, time, torch, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lz4_amd import corpus, device as dev, _lib
 lib = _lib.load()
-n = 2 << 30
+n = int(float(os.environ.get('GIB', '2')) * (1 << 30))
 BS = 1 << 18
 dv = torch.device('cuda', 0)
 kinds = sys.argv[1].split(',') if len(sys.argv) > 1 else ['mixed', 'text', 'random']
@@ -12,7 +12,7 @@ for kind in kinds:
     out = torch.empty((nb, BS), dtype=torch.uint8, device=dv); res = torch.zeros(nb, dtype=torch.int32, device=dv)
     ref_out, ref_res = dev.compress_blocks(src, BS, 0)
     ref_res = ref_res.clone()
-    for waves_per_cu in (0, 8, 16, 24, 32):
+    for waves_per_cu in (4, 6, 8, 10, 12, 16, 20):
         slots = 256 * waves_per_cu
         ws = torch.empty(slots * 131072, dtype=torch.uint8, device=dv) if slots else None
         ts = []
