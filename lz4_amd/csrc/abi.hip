@@ -784,28 +784,28 @@ int64_t lz4hip_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size
         total += (size_t)len[b];
     }
     if (total > dst_cap) return fail(LZ4HIP_ERR_SHORT, "dst_cap too small");
-    if (dense) {
-        HIPCHK(hcopy(dst, d_out.p, total, hipMemcpyDeviceToHost));
-    } else {
+    // the decoded stream, contiguous on the device: the slots themselves when every block
+    // but the last is full (or the frame is linked), else packed by one kernel
+    DevBuf d_flat, d_foff;
+    const uint8_t *d_stream = d_out.as<uint8_t>();
+    if (!dense) {
+        std::vector<uint64_t> foff(nb);
         size_t at = 0;
         for (size_t b = 0; b < nb; b++) {
-            if (len[b])
-                HIPCHK(hcopy(dst + at, d_out.as<uint8_t>() + b * (size_t)bs, (size_t)len[b],
-                                 hipMemcpyDeviceToHost));
+            foff[b] = at;
             at += (size_t)len[b];
         }
+        HIPCHK(d_flat.alloc(total));
+        HIPCHK(d_foff.alloc(nb * 8));
+        HIPCHK(hcopy(d_foff.p, foff.data(), nb * 8, hipMemcpyHostToDevice));
+        HIPCHK(launch_pack_blocks(d_out.as<uint8_t>(), bs, d_len.as<int32_t>(), d_foff.as<uint64_t>(),
+                                  nb, d_flat.as<uint8_t>(), kHostStream));
+        d_stream = d_flat.as<uint8_t>();
     }
+    if (total) HIPCHK(hcopy(dst, d_stream, total, hipMemcpyDeviceToHost));
     if (csum) {  // frame.go:117-131; serial walk over the decoded stream
         uint32_t cs = 0;
-        if (dense) {
-            HIPCHK(launch_xxh32_stream(d_out.as<uint8_t>(), total, d_cs.as<uint32_t>(), kHostStream));
-        } else {
-            DevBuf d_flat;
-            HIPCHK(d_flat.alloc(total));
-            HIPCHK(hcopy(d_flat.p, dst, total, hipMemcpyHostToDevice));
-            HIPCHK(launch_xxh32_stream(d_flat.as<uint8_t>(), total, d_cs.as<uint32_t>(), kHostStream));
-            HIPCHK(hipStreamSynchronize(kHostStream));
-        }
+        HIPCHK(launch_xxh32_stream(d_stream, total, d_cs.as<uint32_t>(), kHostStream));
         HIPCHK(hcopy(&cs, d_cs.p, 4, hipMemcpyDeviceToHost));
         if (cs != want_cs) return fail(LZ4HIP_ERR_FRAME_CHECKSUM, "invalid frame checksum");
     }

@@ -100,6 +100,27 @@ __global__ __launch_bounds__(256) void k_frame_scatter(
     }
 }
 
+// Reader side: decoded blocks sit in fixed-stride slots; pack the ones that are not full
+// into the contiguous stream (block b's out_len bytes go to flat + flat_off[b]).
+__global__ __launch_bounds__(256) void k_pack_blocks(const uint8_t *__restrict__ slots,
+                                                     size_t stride,
+                                                     const int32_t *__restrict__ out_len,
+                                                     const uint64_t *__restrict__ flat_off,
+                                                     size_t nb, uint8_t *__restrict__ flat) {
+    const size_t b = blockIdx.x;
+    if (b >= nb) return;
+    const int32_t l = out_len[b];
+    if (l > 0) wg_copy(flat + flat_off[b], slots + b * stride, (size_t)l, threadIdx.x, 256);
+}
+
+hipError_t launch_pack_blocks(const uint8_t *slots, size_t stride, const int32_t *out_len,
+                              const uint64_t *flat_off, size_t nb, uint8_t *flat, hipStream_t st) {
+    if (nb == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pack_blocks, dim3((unsigned)nb), dim3(256), 0, st, slots, stride, out_len,
+                       flat_off, nb, flat);
+    return hipGetLastError();
+}
+
 hipError_t launch_frame_layout(const int32_t *result, size_t n, uint32_t bs, size_t nb,
                                const uint32_t *xxh, uint64_t first_off, uint64_t *entry_off,
                                uint32_t *size_words, hipStream_t st) {

@@ -273,3 +273,29 @@ def legacy_write_cases(load):
         ("exact_block_iocopy", (bz * 9)[:8 << 20], True, 0, True),
         ("hc_level", bz[:300000], False, 1 << 9, False),
     ]
+
+
+def ragged_frames(compress_block, xxh32):
+    """Independent-block frames whose middle blocks are short (a Writer that was Flush()ed
+    mid-stream: writer.go:148-169).  Returns [(name, frame, expected)]."""
+    import struct
+    pieces = [bytes((i * 31 + k) & 0xFF for i in range(n)) if k % 2 else (b"flush me " * 9000)[:n]
+              for k, n in enumerate([100, 65536, 7, 3000, 65536, 1])]
+    out = []
+    for bsum, csum in ((False, False), (True, True)):
+        flg = 0x60 | (0x10 if bsum else 0) | (0x04 if csum else 0)
+        hdr = bytes([flg, 0x40])
+        f = struct.pack("<I", 0x184D2204) + hdr + bytes([(xxh32(hdr) >> 8) & 0xFF])
+        for d in pieces:
+            c = compress_block(d)
+            if c and len(c) < len(d):
+                f += struct.pack("<I", len(c)) + c
+            else:
+                f += struct.pack("<I", len(d) | 0x80000000) + d
+            if bsum and xxh32(d):
+                f += struct.pack("<I", xxh32(d))
+        f += struct.pack("<I", 0)
+        if csum:
+            f += struct.pack("<I", xxh32(b"".join(pieces)))
+        out.append(("ragged_bsum%d_csum%d" % (bsum, csum), f, b"".join(pieces)))
+    return out

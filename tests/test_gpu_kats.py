@@ -153,6 +153,25 @@ def test_legacy_write(i, oracle):
         assert lz.Reader(io.BytesIO(out.getvalue())).Read() == data
 
 
+@pytest.mark.parametrize("i", range(2))
+def test_ragged_frames(i, oracle):
+    """Short blocks in the middle of a frame: decoded slots are packed on the device."""
+    import lz4_amd as lz
+
+    def cb(d):
+        try:
+            return oracle.CompressBlock(d, len(d))[1]
+        except oracle.ErrInvalidSourceShortBuffer:
+            return b""
+    name, frame, want = kats.ragged_frames(cb, oracle.ChecksumZero)[i]
+    assert lz.frame.uncompress_frame(frame) == want, name
+    bad = bytearray(frame)
+    bad[-1] ^= 1
+    if i == 1:
+        with pytest.raises(lz.ErrInvalidFrameChecksum):
+            lz.frame.uncompress_frame(bytes(bad))
+
+
 def test_malformed_block_checksum():
     """reader_test.go: malformed.block.lz4 => invalid block checksum."""
     import lz4_amd as lz

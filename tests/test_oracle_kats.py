@@ -193,6 +193,17 @@ def test_legacy_write_round_trip(i):
         assert o.frame_uncompress(f, len(data) + 16) == data
 
 
+@pytest.mark.parametrize("i", range(2))
+def test_ragged_frames(i):
+    def cb(d):
+        try:
+            return o.CompressBlock(d, len(d))[1]
+        except o.ErrInvalidSourceShortBuffer:
+            return b""
+    name, frame, want = kats.ragged_frames(cb, o.ChecksumZero)[i]
+    assert o.frame_uncompress(frame, len(want) + 16) == want, name
+
+
 def test_malformed_block_checksum():
     with pytest.raises(ValueError) as e:
         o.frame_uncompress(load("malformed.block.lz4"), 1 << 22)
