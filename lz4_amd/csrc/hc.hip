@@ -15,7 +15,38 @@
 
 namespace lz4hip {
 
-constexpr int kHcSlotWords = 2 * (1 << 16);
+// Per-slot workspace: hashTable u32[65536], then the chain table, 8 bytes per entry.
+// The reference's chainTable[p & 0xffff] holds the previous position with p's hash
+// (block.go:382-383).  Here the entry holds FOUR links: the distances from p to the 1st,
+// 2nd, 3rd and 4th previous positions of its chain, as u16 (0 = none, or 65536 or more
+// away: the reference's walk stops there anyway, `si-next < winSize`, :355).  Links of
+// older positions never change, so links 2..4 are link 1 plus the links read from the
+// previous head's entry at insertion time.  A walk then costs one dependent fetch per
+// four candidates instead of one per candidate, in the same candidate order.
+constexpr int kHcSlotWords = 3 * (1 << 16);
+
+__device__ __forceinline__ int hc_link(const uint2 e, int k) {
+    const uint32_t w = k < 2 ? e.x : e.y;
+    return (int)((k & 1) ? (w >> 16) : (w & 0xFFFFu));
+}
+
+// chainTable[p] = hashTable[hh]; hashTable[hh] = p  (block.go:382-383,401-402), one lane.
+__device__ __forceinline__ void hc_insert(uint32_t *hash_table, uint2 *chain_table, uint32_t hh, int p) {
+    const int head = (int)hash_table[hh];
+    uint32_t d[4] = {0, 0, 0, 0};
+    if (head > 0 && p - head < kWinSize) {
+        d[0] = (uint32_t)(p - head);
+        const uint2 e = chain_table[head & kWinMask];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const uint32_t l = (uint32_t)hc_link(e, k);
+            if (l == 0 || d[0] + l >= (uint32_t)kWinSize) break;
+            d[k + 1] = d[0] + l;
+        }
+    }
+    chain_table[p & kWinMask] = make_uint2(d[0] | (d[1] << 16), d[2] | (d[3] << 16));
+    hash_table[hh] = (uint32_t)p;
+}
 
 // Prefix length of block.go:361-372 for one candidate (lane-private loop).
 __device__ __forceinline__ int hc_prefix_len(const uint8_t *s, int next, int si, int lim) {
@@ -40,6 +71,76 @@ __device__ __forceinline__ int wave_max(int v) {
     return v;
 }
 
+// Inserts positions p0 .. p0+n-1 in order (block.go:394-405 without the window clamp:
+// every position's 4-byte value is then its own bytes), 64 per round, all lanes at once.
+// Sequential semantics: each position links to the latest earlier position with its
+// hash -- inside the round if there is one, else the table's head -- and the table keeps
+// the last one.  Lanes without an earlier twin gather head and head's links together;
+// lanes with a twin take the twin's position and (twin's links + distance), resolved in
+// dependency order with shuffles: as many steps as the longest same-hash run, no memory
+// round trip inside (a run of equal bytes resolves in registers).
+__device__ __forceinline__ void hc_insert_run(uint32_t *hash_table, uint2 *chain_table,
+                                              const uint8_t *__restrict__ s, int p0, int n,
+                                              int lane) {
+    for (int base = 0; base < n; base += kWave) {
+        const int cnt = n - base < kWave ? n - base : kWave;
+        const bool act = lane < cnt;
+        const int p = p0 + base + lane;
+        const uint32_t hh = act ? hash4(ld32(s + p)) : 0xFFFFFFFFu;
+        int twin = -1;        // nearest earlier lane with my hash
+        bool later = false;   // a later lane has my hash: it, not I, ends up in the table
+        for (int i = 0; i < cnt; i++) {
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)hh, i);
+            if (act && hh == hi) {
+                if (lane > i) twin = i;
+                if (lane < i) later = true;
+            }
+        }
+        uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+        bool done = !act;
+        if (act && twin < 0) {
+            const int head = (int)hash_table[hh];
+            if (head > 0 && p - head < kWinSize) {
+                d0 = (uint32_t)(p - head);
+                const uint2 e = chain_table[head & kWinMask];
+                const uint32_t l0 = (uint32_t)hc_link(e, 0), l1 = (uint32_t)hc_link(e, 1),
+                               l2 = (uint32_t)hc_link(e, 2);
+                if (l0 && d0 + l0 < (uint32_t)kWinSize) {
+                    d1 = d0 + l0;
+                    if (l1 && d0 + l1 < (uint32_t)kWinSize) {
+                        d2 = d0 + l1;
+                        if (l2 && d0 + l2 < (uint32_t)kWinSize) d3 = d0 + l2;
+                    }
+                }
+            }
+            done = true;
+        }
+        // twins: my links are the twin's, shifted by our distance
+        while (ballot(!done)) {
+            const int src = twin < 0 ? lane : twin;
+            const uint32_t t0 = (uint32_t)__shfl((int)d0, src), t1 = (uint32_t)__shfl((int)d1, src),
+                           t2 = (uint32_t)__shfl((int)d2, src);
+            const bool tdone = __shfl((int)done, src) != 0;
+            if (!done && tdone) {
+                const uint32_t dd = (uint32_t)(lane - twin);
+                d0 = dd;
+                d1 = t0 ? dd + t0 : 0;  // dd < 64: the sums stay inside the window unless t* is near it
+                d2 = (d1 && t1) ? dd + t1 : 0;
+                d3 = (d2 && t2) ? dd + t2 : 0;
+                if (d1 >= (uint32_t)kWinSize) d1 = d2 = d3 = 0;
+                if (d2 >= (uint32_t)kWinSize) d2 = d3 = 0;
+                if (d3 >= (uint32_t)kWinSize) d3 = 0;
+                done = true;
+            }
+        }
+        if (act) {
+            chain_table[p & kWinMask] = make_uint2(d0 | (d1 << 16), d2 | (d3 << 16));
+            if (!later) hash_table[hh] = (uint32_t)p;
+        }
+        __syncthreads();  // the next round gathers what this one stored
+    }
+}
+
 __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ src,
                                                     size_t n_total, uint32_t block_size,
                                                     uint32_t depth, int dst_mode, uint32_t dst_len_x,
@@ -48,7 +149,7 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                                                     uint32_t *__restrict__ ws, size_t nb) {
     const int lane = lane_id();
     uint32_t *hash_table = ws + (size_t)blockIdx.x * kHcSlotWords;
-    uint32_t *chain_table = hash_table + (1 << 16);
+    uint2 *chain_table = reinterpret_cast<uint2 *>(hash_table + (1 << 16));
     if (depth == 0) depth = kWinSize;  // block.go:343-345
 
     for (size_t b = blockIdx.x; b < nb; b += gridDim.x) {
@@ -85,13 +186,43 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                 // stop once that maximum is reached: the rest of the chain changes nothing.
                 const int ml_max = (lim + 7) & ~7;
                 while (tries > 0 && next > 0 && si - next < kWinSize && m_len < ml_max) {
-                    // collect up to 64 chain entries, one per lane
-                    int mine = 0, cnt = 0;
-                    while (cnt < kWave && tries > 0 && next > 0 && si - next < kWinSize) {
-                        if (lane == cnt) mine = next;
-                        cnt++;
-                        tries--;
-                        next = (int)chain_table[next & kWinMask];
+                    // collect up to 64 chain entries, one per lane: `next` itself, then up
+                    // to four per fetched chain entry
+                    int mine = 0;
+                    if (lane == 0) mine = next;
+                    int cnt = 1;
+                    tries--;
+                    int cur = next;
+                    next = 0;
+                    bool resume = false;  // batch ended right after a fourth link: fetch once more
+                    while (cnt < kWave && tries > 0) {
+                        const uint2 e = chain_table[cur & kWinMask];
+                        int nv = 0;  // leading links that exist and lie inside the window
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int l = hc_link(e, k);
+                            if (nv == k && l != 0 && si - (cur - l) < kWinSize) nv = k + 1;
+                        }
+                        int nt = nv;
+                        if (nt > kWave - cnt) nt = kWave - cnt;
+                        if ((uint32_t)nt > tries) nt = (int)tries;
+                        const int k = lane - cnt;
+                        if (k >= 0 && k < nt) mine = cur - hc_link(e, k);
+                        cnt += nt;
+                        tries -= (uint32_t)nt;
+                        if (nt < 4) {
+                            // chain over (nt == nv), depth spent, or out of lanes: then the
+                            // first link not taken starts the next batch
+                            if (nt < nv && tries > 0) next = cur - hc_link(e, nt);
+                            resume = false;
+                            break;
+                        }
+                        cur -= hc_link(e, 3);
+                        resume = true;
+                    }
+                    if (resume && tries > 0) {
+                        const int l = hc_link(chain_table[cur & kWinMask], 0);
+                        if (l != 0) next = cur - l;  // window check: loop condition
                     }
                     int ml = 0;
                     if (lane < cnt) ml = hc_prefix_len(s, mine, si, lim);
@@ -104,10 +235,7 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                     }
                 }
             }
-            if (lane == 0) {
-                chain_table[si & kWinMask] = hash_table[h];
-                hash_table[h] = (uint32_t)si;
-            }
+            if (lane == 0) hc_insert(hash_table, chain_table, h, si);
             __syncthreads();
 
             if (m_len == 0) {  // :386-389
@@ -120,16 +248,16 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                 const int wsn = si + m_len - kWinSize;
                 if (wsn > p) p = wsn;
                 const int end = si + m_len;
-                if (lane == 0) {
+                if (wsn <= si + 1) {
+                    hc_insert_run(hash_table, chain_table, s, p, end - p, lane);
+                } else if (lane == 0) {
                     // The reference rolls the 4-byte value from the one at si
                     // (:399-400).  When the window clamp skips positions (match
                     // longer than 64 KiB) the first three values mix old and new
                     // bytes; reproduce that, it decides which slots are written.
                     for (; p < end; p++) {
                         match = (match >> 8) | ((uint32_t)s[p + 3] << 24);
-                        const uint32_t hh = hash4(match);
-                        chain_table[p & kWinMask] = hash_table[hh];
-                        hash_table[hh] = (uint32_t)p;
+                        hc_insert(hash_table, chain_table, hash4(match), p);
                     }
                 }
                 __syncthreads();
