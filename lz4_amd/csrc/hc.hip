@@ -15,37 +15,37 @@
 
 namespace lz4hip {
 
-// Per-slot workspace: hashTable u32[65536], then the chain table, 8 bytes per entry.
+// Per-slot workspace: hashTable u32[65536], then the chain table, kHcLinks u16 per entry.
 // The reference's chainTable[p & 0xffff] holds the previous position with p's hash
-// (block.go:382-383).  Here the entry holds FOUR links: the distances from p to the 1st,
-// 2nd, 3rd and 4th previous positions of its chain, as u16 (0 = none, or 65536 or more
-// away: the reference's walk stops there anyway, `si-next < winSize`, :355).  Links of
-// older positions never change, so links 2..4 are link 1 plus the links read from the
-// previous head's entry at insertion time.  A walk then costs one dependent fetch per
-// four candidates instead of one per candidate, in the same candidate order.
-constexpr int kHcSlotWords = 3 * (1 << 16);
+// (block.go:382-383).  Here the entry holds the distances from p to the 1st .. kHcLinks-th
+// previous positions of its chain, as u16 (0 = none, or 65536 or more away: the
+// reference's walk stops there anyway, `si-next < winSize`, :355).  Links of older
+// positions never change, so links 2.. are link 1 plus the links read from the previous
+// head's entry at insertion time.  A walk then costs one dependent fetch per kHcLinks
+// candidates instead of one per candidate, in the same candidate order.
+constexpr int kHcLinks = 16;
+constexpr int kHcSlotWords = (1 << 16) + (1 << 16) * kHcLinks / 2;
 
-__device__ __forceinline__ int hc_link(const uint2 e, int k) {
-    const uint32_t w = k < 2 ? e.x : e.y;
-    return (int)((k & 1) ? (w >> 16) : (w & 0xFFFFu));
-}
-
-// chainTable[p] = hashTable[hh]; hashTable[hh] = p  (block.go:382-383,401-402), one lane.
-__device__ __forceinline__ void hc_insert(uint32_t *hash_table, uint2 *chain_table, uint32_t hh, int p) {
+// chainTable[p] = hashTable[hh]; hashTable[hh] = p  (block.go:382-383,401-402), by the
+// whole wave: lane j < kHcLinks builds and stores link j.
+__device__ __forceinline__ void hc_insert(uint32_t *hash_table, uint16_t *chain_table, uint32_t hh,
+                                          int p, int lane) {
     const int head = (int)hash_table[hh];
-    uint32_t d[4] = {0, 0, 0, 0};
-    if (head > 0 && p - head < kWinSize) {
-        d[0] = (uint32_t)(p - head);
-        const uint2 e = chain_table[head & kWinMask];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const uint32_t l = (uint32_t)hc_link(e, k);
-            if (l == 0 || d[0] + l >= (uint32_t)kWinSize) break;
-            d[k + 1] = d[0] + l;
+    if (lane < kHcLinks) {
+        uint32_t l = 0;
+        if (head > 0 && p - head < kWinSize) {
+            const uint32_t d0 = (uint32_t)(p - head);
+            if (lane == 0) {
+                l = d0;
+            } else {
+                const uint32_t hl = chain_table[(size_t)(head & kWinMask) * kHcLinks + lane - 1];
+                if (hl != 0 && d0 + hl < (uint32_t)kWinSize) l = d0 + hl;
+            }
         }
+        chain_table[(size_t)(p & kWinMask) * kHcLinks + lane] = (uint16_t)l;
     }
-    chain_table[p & kWinMask] = make_uint2(d[0] | (d[1] << 16), d[2] | (d[3] << 16));
-    hash_table[hh] = (uint32_t)p;
+    __syncthreads();  // every lane has read the old head
+    if (lane == 0) hash_table[hh] = (uint32_t)p;
 }
 
 // Prefix length of block.go:361-372 for one candidate (lane-private loop).
@@ -79,9 +79,10 @@ __device__ __forceinline__ int wave_max(int v) {
 // lanes with a twin take the twin's position and (twin's links + distance), resolved in
 // dependency order with shuffles: as many steps as the longest same-hash run, no memory
 // round trip inside (a run of equal bytes resolves in registers).
-__device__ __forceinline__ void hc_insert_run(uint32_t *hash_table, uint2 *chain_table,
+__device__ __forceinline__ void hc_insert_run(uint32_t *hash_table, uint16_t *chain_table,
                                               const uint8_t *__restrict__ s, int p0, int n,
                                               int lane) {
+    typedef uint4 __attribute__((may_alias)) uint4_a;
     for (int base = 0; base < n; base += kWave) {
         const int cnt = n - base < kWave ? n - base : kWave;
         const bool act = lane < cnt;
@@ -96,45 +97,68 @@ __device__ __forceinline__ void hc_insert_run(uint32_t *hash_table, uint2 *chain
                 if (lane < i) later = true;
             }
         }
-        uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+        // d[k]: my links, two u16 per register (the entry's memory image)
+        uint32_t d[kHcLinks / 2];
+#pragma unroll
+        for (int k = 0; k < kHcLinks / 2; k++) d[k] = 0;
         bool done = !act;
+        uint32_t shift = 0;  // what to add to the links I inherit
         if (act && twin < 0) {
             const int head = (int)hash_table[hh];
             if (head > 0 && p - head < kWinSize) {
-                d0 = (uint32_t)(p - head);
-                const uint2 e = chain_table[head & kWinMask];
-                const uint32_t l0 = (uint32_t)hc_link(e, 0), l1 = (uint32_t)hc_link(e, 1),
-                               l2 = (uint32_t)hc_link(e, 2);
-                if (l0 && d0 + l0 < (uint32_t)kWinSize) {
-                    d1 = d0 + l0;
-                    if (l1 && d0 + l1 < (uint32_t)kWinSize) {
-                        d2 = d0 + l1;
-                        if (l2 && d0 + l2 < (uint32_t)kWinSize) d3 = d0 + l2;
-                    }
+                shift = (uint32_t)(p - head);
+                const uint4_a *e = (const uint4_a *)(chain_table + (size_t)(head & kWinMask) * kHcLinks);
+#pragma unroll
+                for (int q = 0; q < kHcLinks / 8; q++) {
+                    const uint4 v = e[q];
+                    d[4 * q] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w;
                 }
             }
+        }
+        // lanes with a twin inherit the twin's FINAL links: resolved in dependency order
+        // with shuffles (as many steps as the longest same-hash run of the round)
+        // first turn "inherited links" into "my links" for the lanes that read the table
+        auto finish = [&](uint32_t sh) {
+            // my link 0 = sh; my link j = sh + inherited link j-1 (while present and in window)
+            uint32_t prev = sh;  // value going into the low half of d[0]
+            bool alive = sh != 0;
+#pragma unroll
+            for (int k = 0; k < kHcLinks / 2; k++) {
+                const uint32_t in_lo = d[k] & 0xFFFFu, in_hi = d[k] >> 16;  // inherited links 2k, 2k+1
+                const uint32_t lo = alive ? prev : 0;                        // my link 2k
+                uint32_t hi = 0;                                             // my link 2k+1 = sh + inherited 2k
+                if (alive && in_lo != 0 && sh + in_lo < (uint32_t)kWinSize) hi = sh + in_lo;
+                else alive = false;
+                // my link 2k+2 = sh + inherited 2k+1
+                uint32_t nxt = 0;
+                if (alive && in_hi != 0 && sh + in_hi < (uint32_t)kWinSize) nxt = sh + in_hi;
+                else alive = false;
+                d[k] = lo | (hi << 16);
+                prev = nxt;
+            }
+        };
+        if (act && twin < 0) {
+            finish(shift);
             done = true;
         }
-        // twins: my links are the twin's, shifted by our distance
         while (ballot(!done)) {
             const int src = twin < 0 ? lane : twin;
-            const uint32_t t0 = (uint32_t)__shfl((int)d0, src), t1 = (uint32_t)__shfl((int)d1, src),
-                           t2 = (uint32_t)__shfl((int)d2, src);
+            uint32_t t[kHcLinks / 2];
+#pragma unroll
+            for (int k = 0; k < kHcLinks / 2; k++) t[k] = (uint32_t)__shfl((int)d[k], src);
             const bool tdone = __shfl((int)done, src) != 0;
             if (!done && tdone) {
-                const uint32_t dd = (uint32_t)(lane - twin);
-                d0 = dd;
-                d1 = t0 ? dd + t0 : 0;  // dd < 64: the sums stay inside the window unless t* is near it
-                d2 = (d1 && t1) ? dd + t1 : 0;
-                d3 = (d2 && t2) ? dd + t2 : 0;
-                if (d1 >= (uint32_t)kWinSize) d1 = d2 = d3 = 0;
-                if (d2 >= (uint32_t)kWinSize) d2 = d3 = 0;
-                if (d3 >= (uint32_t)kWinSize) d3 = 0;
+#pragma unroll
+                for (int k = 0; k < kHcLinks / 2; k++) d[k] = t[k];
+                finish((uint32_t)(lane - twin));
                 done = true;
             }
         }
         if (act) {
-            chain_table[p & kWinMask] = make_uint2(d0 | (d1 << 16), d2 | (d3 << 16));
+            uint4_a *e = (uint4_a *)(chain_table + (size_t)(p & kWinMask) * kHcLinks);
+#pragma unroll
+            for (int q = 0; q < kHcLinks / 8; q++)
+                e[q] = make_uint4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
             if (!later) hash_table[hh] = (uint32_t)p;
         }
         __syncthreads();  // the next round gathers what this one stored
@@ -149,7 +173,7 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                                                     uint32_t *__restrict__ ws, size_t nb) {
     const int lane = lane_id();
     uint32_t *hash_table = ws + (size_t)blockIdx.x * kHcSlotWords;
-    uint2 *chain_table = reinterpret_cast<uint2 *>(hash_table + (1 << 16));
+    uint16_t *chain_table = reinterpret_cast<uint16_t *>(hash_table + (1 << 16));
     if (depth == 0) depth = kWinSize;  // block.go:343-345
 
     for (size_t b = blockIdx.x; b < nb; b += gridDim.x) {
@@ -187,41 +211,40 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                 const int ml_max = (lim + 7) & ~7;
                 while (tries > 0 && next > 0 && si - next < kWinSize && m_len < ml_max) {
                     // collect up to 64 chain entries, one per lane: `next` itself, then up
-                    // to four per fetched chain entry
+                    // to kHcLinks per fetched chain entry (lane j < kHcLinks loads link j)
                     int mine = 0;
                     if (lane == 0) mine = next;
                     int cnt = 1;
                     tries--;
                     int cur = next;
                     next = 0;
-                    bool resume = false;  // batch ended right after a fourth link: fetch once more
+                    bool resume = false;  // batch ended right after a last link: fetch once more
                     while (cnt < kWave && tries > 0) {
-                        const uint2 e = chain_table[cur & kWinMask];
-                        int nv = 0;  // leading links that exist and lie inside the window
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const int l = hc_link(e, k);
-                            if (nv == k && l != 0 && si - (cur - l) < kWinSize) nv = k + 1;
-                        }
+                        int l = 0;
+                        if (lane < kHcLinks) l = chain_table[(size_t)(cur & kWinMask) * kHcLinks + lane];
+                        // links are ordered and prefix-complete: count the ones inside the window
+                        const uint64_t okm = ballot(lane < kHcLinks && l != 0 && si - (cur - l) < kWinSize);
+                        const int nv = __builtin_popcountll(okm);
                         int nt = nv;
                         if (nt > kWave - cnt) nt = kWave - cnt;
                         if ((uint32_t)nt > tries) nt = (int)tries;
                         const int k = lane - cnt;
-                        if (k >= 0 && k < nt) mine = cur - hc_link(e, k);
+                        const int lk = __shfl(l, k & (kWave - 1));
+                        if (k >= 0 && k < nt) mine = cur - lk;
                         cnt += nt;
                         tries -= (uint32_t)nt;
-                        if (nt < 4) {
+                        if (nt < kHcLinks) {
                             // chain over (nt == nv), depth spent, or out of lanes: then the
                             // first link not taken starts the next batch
-                            if (nt < nv && tries > 0) next = cur - hc_link(e, nt);
+                            if (nt < nv && tries > 0) next = cur - (int)rfl((uint32_t)__shfl(l, nt));
                             resume = false;
                             break;
                         }
-                        cur -= hc_link(e, 3);
+                        cur -= (int)rfl((uint32_t)__shfl(l, kHcLinks - 1));
                         resume = true;
                     }
                     if (resume && tries > 0) {
-                        const int l = hc_link(chain_table[cur & kWinMask], 0);
+                        const int l = chain_table[(size_t)(cur & kWinMask) * kHcLinks];
                         if (l != 0) next = cur - l;  // window check: loop condition
                     }
                     int ml = 0;
@@ -235,7 +258,7 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                     }
                 }
             }
-            if (lane == 0) hc_insert(hash_table, chain_table, h, si);
+            hc_insert(hash_table, chain_table, h, si, lane);
             __syncthreads();
 
             if (m_len == 0) {  // :386-389
@@ -250,14 +273,14 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                 const int end = si + m_len;
                 if (wsn <= si + 1) {
                     hc_insert_run(hash_table, chain_table, s, p, end - p, lane);
-                } else if (lane == 0) {
+                } else {
                     // The reference rolls the 4-byte value from the one at si
                     // (:399-400).  When the window clamp skips positions (match
                     // longer than 64 KiB) the first three values mix old and new
                     // bytes; reproduce that, it decides which slots are written.
                     for (; p < end; p++) {
                         match = (match >> 8) | ((uint32_t)s[p + 3] << 24);
-                        hc_insert(hash_table, chain_table, hash4(match), p);
+                        hc_insert(hash_table, chain_table, hash4(match), p, lane);
                     }
                 }
                 __syncthreads();
