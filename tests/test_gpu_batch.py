@@ -125,6 +125,51 @@ def test_decode_errors_per_block_never_write_oob(T, oracle):
         assert bool((out[0, dlen:] == 0xAB).all().item()), "wrote beyond dst_len"
 
 
+def test_decode_mutated_blocks_match_oracle_and_stay_in_bounds(T, oracle):
+    """Fuzz in the spirit of fuzz/lz4.go's Uncompress target: 3000 valid blocks with a few
+    random byte mutations / truncations each, decoded as ONE batch with a dst_len that is
+    sometimes too small.  Per block the result must be the oracle's: same error-or-length,
+    same bytes, and nothing written at or beyond dst_len (0xAB guard)."""
+    from lz4_amd import corpus, device as dev
+    rng = np.random.default_rng(20240607)
+    kinds = ("text", "binary", "mixed")
+    blobs = []
+    for i in range(3000):
+        n = int(rng.integers(20, 6000))
+        raw = corpus.generate(kinds[i % 3], int(rng.integers(0, 1 << 24)), n)
+        k, c = oracle.CompressBlock(raw, oracle.CompressBlockBound(n))
+        c = bytearray(c)
+        for _ in range(int(rng.integers(0, 4))):          # 0..3 mutations
+            j = int(rng.integers(0, len(c)))
+            c[j] = int(rng.integers(0, 256))
+        if rng.integers(0, 8) == 0:
+            c = c[:int(rng.integers(1, len(c) + 1))]      # truncation
+        blobs.append(bytes(c))
+    stride = 6144
+    dlen = 6000
+    # one launch takes one dst_len: full size, then two that are too small for most blocks
+    blob = b"".join(blobs)
+    offs = np.cumsum([0] + [len(b) for b in blobs[:-1]]).astype(np.int64)
+    lens = np.array([len(b) for b in blobs], dtype=np.int32)
+    d_blob = _dev(T, blob)
+    for dst_len in (dlen, 700, 64):
+        out = T.full((len(blobs), stride), 0xAB, dtype=T.uint8, device="cuda")
+        o, ol = dev.uncompress_blocks(d_blob, T.from_numpy(offs).cuda(), T.from_numpy(lens).cuda(),
+                                      dst_len, out=out, dst_stride=stride)
+        got = ol.cpu().numpy()
+        outs = o.cpu().numpy()
+        assert (outs[:, dst_len:] == 0xAB).all(), "wrote at or beyond dst_len"
+        bad = 0
+        for i, c in enumerate(blobs):
+            want, wd = oracle.decodeBlock(c, dst_len)
+            assert (got[i] < 0) == (want < 0), (dst_len, i, got[i], want)
+            if want >= 0:
+                assert got[i] == want and outs[i, :want].tobytes() == wd[:want].tobytes(), (dst_len, i)
+            else:
+                bad += 1
+        assert 0 < bad < len(blobs)
+
+
 @pytest.mark.parametrize("n", [0, 1, 65535, 65536, 65537, 3 * 65536, 1000000])
 @pytest.mark.parametrize("flags", [0, 1, 2, 3, 2 | 8, 3 | 8, 2 | 4])
 def test_frame_compress_device_vs_oracle(T, oracle, n, flags):
