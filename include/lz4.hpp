@@ -293,7 +293,7 @@ class Reader {
     }
     // Upper bound of the decoded size from the block index (lz4stream/block.go:279-317).
     static size_t decoded_bound(const Bytes &f, size_t si, uint32_t bs, uint32_t flags) {
-        size_t nb = 0;
+        size_t nb = 0;  // bytes
         const bool legacy = flags & LZ4HIP_F_LEGACY, bsum = flags & LZ4HIP_F_BLOCK_CHECKSUM;
         while (si + 4 <= f.size()) {
             uint32_t w;
@@ -301,10 +301,13 @@ class Reader {
             si += 4;
             if (legacy && w == 0x184C2102u) continue;
             if (!legacy && w == 0) break;
-            si += (w & 0x7FFFFFFFu) + (bsum ? 4 : 0);
-            nb++;
+            const size_t size = w & 0x7FFFFFFFu;
+            si += size + (bsum ? 4 : 0);
+            // a stored block keeps its size, a compressed one grows at most 255-fold
+            const size_t grow = (w >> 31) ? size : size * 255;
+            nb += grow < bs ? grow : bs;
         }
-        return nb * (size_t)bs;
+        return nb;
     }
     Error fill() {
         if (state_ == State::Error) return err_;

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -745,67 +746,82 @@ int64_t lz4hip_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size
         return 0;
     }
 
-    DevBuf d_src, d_off, d_sw, d_out, d_len, d_xxh, d_cs;
+    // Device memory is bounded by the caller's dst_cap, not by n_blocks * block_size: a
+    // frame of many short blocks (a Writer flushed often) must not ask for n_blocks full
+    // slots.  Independent blocks decode a chunk at a time into <= 1 GiB of fixed-stride
+    // slots and are packed into the contiguous stream; linked blocks decode straight
+    // into it.  Errors keep stream order (lz4stream/block.go:187-194): chunks run in
+    // order and each chunk is checked front to back before the next starts.
+    DevBuf d_src, d_off, d_sw, d_slots, d_flat, d_len, d_xxh, d_cs, d_foff;
+    // stream buffer: no more than the blocks can decode to (a compressed block grows at
+    // most 255-fold, a stored one not at all), no more than the caller can take, plus one
+    // block of slack so that only the final check decides "dst_cap too small"
+    size_t need = 0;
+    for (size_t b = 0; b < nb; b++) {
+        const size_t sz = sw[b] & 0x7FFFFFFFu;
+        const size_t grow = (sw[b] >> 31) ? sz : sz * 255;
+        need += grow < bs ? grow : bs;
+    }
+    const size_t flat_cap = (need < dst_cap ? need : dst_cap) + (size_t)bs;
+    const size_t chunk = independent ? std::max<size_t>(1, std::min<size_t>(nb, (1ull << 30) / bs)) : nb;
     HIPCHK(d_src.alloc(n));
     HIPCHK(d_off.alloc(nb * 8));
     HIPCHK(d_sw.alloc(nb * 4));
-    HIPCHK(d_out.alloc(nb * (size_t)bs));
-    HIPCHK(d_len.alloc(nb * 4));
-    HIPCHK(d_xxh.alloc(nb * 4));
+    HIPCHK(d_flat.alloc(flat_cap + 16));
+    HIPCHK(d_len.alloc(chunk * 4));
+    HIPCHK(d_xxh.alloc(chunk * 4));
+    HIPCHK(d_foff.alloc(chunk * 8));
     HIPCHK(d_cs.alloc(4));
+    if (independent) HIPCHK(d_slots.alloc(chunk * (size_t)bs));
     HIPCHK(hcopy(d_src.p, src, n, hipMemcpyHostToDevice));
     HIPCHK(hcopy(d_off.p, off.data(), nb * 8, hipMemcpyHostToDevice));
     HIPCHK(hcopy(d_sw.p, sw.data(), nb * 4, hipMemcpyHostToDevice));
-    DevBuf d_ooff;  // linked frames: where each block's output starts in d_out
-    if (independent) {
-        HIPCHK(launch_decode_any(d_src.as<uint8_t>(), d_off.as<uint64_t>(), d_sw.as<uint32_t>(), nb,
-                                 d_out.as<uint8_t>(), bs, bs, 0, d_len.as<int32_t>(), kHostStream));
-    } else {  // reader.go:86-90,176-189: dependent blocks decode in order, output packed
-        HIPCHK(d_ooff.alloc(nb * 8));
-        HIPCHK(launch_decode2_linked(d_src.as<uint8_t>(), d_off.as<uint64_t>(), d_sw.as<uint32_t>(),
-                                     nb, d_out.as<uint8_t>(), bs, d_len.as<int32_t>(),
-                                     d_ooff.as<uint64_t>(), kHostStream));
-    }
-    if (bsum)  // verified on the DECODED bytes: lz4stream/block.go:330-335
-        HIPCHK(launch_xxh32_blocks(d_out.as<uint8_t>(), nb * (size_t)bs, bs,
-                                   independent ? nullptr : d_ooff.as<uint64_t>(),
-                                   d_len.as<int32_t>(), nb, d_xxh.as<uint32_t>(), kHostStream));
-    std::vector<int32_t> len(nb);
-    std::vector<uint32_t> got(nb);
-    HIPCHK(hcopy(len.data(), d_len.p, nb * 4, hipMemcpyDeviceToHost));
-    if (bsum) HIPCHK(hcopy(got.data(), d_xxh.p, nb * 4, hipMemcpyDeviceToHost));
-    // first failing block wins, in stream order (lz4stream/block.go:187-194)
+    std::vector<int32_t> len(chunk);
+    std::vector<uint32_t> got(chunk);
+    std::vector<uint64_t> foff(chunk);
     size_t total = 0;
-    bool dense = true;  // every block but the last is full (or packed): one contiguous copy
-    for (size_t b = 0; b < nb; b++) {
-        if (len[b] < 0) return fail(LZ4HIP_ERR_BLOCK, "invalid source or destination buffer too short");
-        if (bsum && got[b] != want[b]) return fail(LZ4HIP_ERR_BLOCK_CHECKSUM, "invalid block checksum");
-        if (independent && b + 1 < nb && (uint32_t)len[b] != bs) dense = false;
-        total += (size_t)len[b];
-    }
-    if (total > dst_cap) return fail(LZ4HIP_ERR_SHORT, "dst_cap too small");
-    // the decoded stream, contiguous on the device: the slots themselves when every block
-    // but the last is full (or the frame is linked), else packed by one kernel
-    DevBuf d_flat, d_foff;
-    const uint8_t *d_stream = d_out.as<uint8_t>();
-    if (!dense) {
-        std::vector<uint64_t> foff(nb);
-        size_t at = 0;
-        for (size_t b = 0; b < nb; b++) {
-            foff[b] = at;
-            at += (size_t)len[b];
+    for (size_t b0 = 0; b0 < nb; b0 += chunk) {
+        const size_t c = std::min(chunk, nb - b0);
+        if (independent) {
+            HIPCHK(launch_decode_any(d_src.as<uint8_t>(), d_off.as<uint64_t>() + b0,
+                                     d_sw.as<uint32_t>() + b0, c, d_slots.as<uint8_t>(), bs, bs, 0,
+                                     d_len.as<int32_t>(), kHostStream));
+            if (bsum)  // verified on the DECODED bytes: lz4stream/block.go:330-335
+                HIPCHK(launch_xxh32_blocks(d_slots.as<uint8_t>(), c * (size_t)bs, bs, nullptr,
+                                           d_len.as<int32_t>(), c, d_xxh.as<uint32_t>(), kHostStream));
+        } else {  // reader.go:86-90,176-189: dependent blocks decode in order, output packed
+            HIPCHK(launch_decode2_linked(d_src.as<uint8_t>(), d_off.as<uint64_t>(), d_sw.as<uint32_t>(),
+                                         nb, d_flat.as<uint8_t>(), bs, flat_cap, d_len.as<int32_t>(),
+                                         d_foff.as<uint64_t>(), kHostStream));
+            if (bsum)
+                HIPCHK(launch_xxh32_blocks(d_flat.as<uint8_t>(), flat_cap, bs, d_foff.as<uint64_t>(),
+                                           d_len.as<int32_t>(), nb, d_xxh.as<uint32_t>(), kHostStream));
         }
-        HIPCHK(d_flat.alloc(total));
-        HIPCHK(d_foff.alloc(nb * 8));
-        HIPCHK(hcopy(d_foff.p, foff.data(), nb * 8, hipMemcpyHostToDevice));
-        HIPCHK(launch_pack_blocks(d_out.as<uint8_t>(), bs, d_len.as<int32_t>(), d_foff.as<uint64_t>(),
-                                  nb, d_flat.as<uint8_t>(), kHostStream));
-        d_stream = d_flat.as<uint8_t>();
+        HIPCHK(hcopy(len.data(), d_len.p, c * 4, hipMemcpyDeviceToHost));
+        if (bsum) HIPCHK(hcopy(got.data(), d_xxh.p, c * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < c; i++) {
+            if (len[i] < 0) {
+                // a linked block that found no room left in the stream buffer
+                if (!independent && total + bs > flat_cap)
+                    return fail(LZ4HIP_ERR_SHORT, "dst_cap too small");
+                return fail(LZ4HIP_ERR_BLOCK, "invalid source or destination buffer too short");
+            }
+            if (bsum && got[i] != want[b0 + i])
+                return fail(LZ4HIP_ERR_BLOCK_CHECKSUM, "invalid block checksum");
+            foff[i] = total;
+            total += (size_t)len[i];
+            if (total > dst_cap) return fail(LZ4HIP_ERR_SHORT, "dst_cap too small");
+        }
+        if (independent) {
+            HIPCHK(hcopy(d_foff.p, foff.data(), c * 8, hipMemcpyHostToDevice));
+            HIPCHK(launch_pack_blocks(d_slots.as<uint8_t>(), bs, d_len.as<int32_t>(),
+                                      d_foff.as<uint64_t>(), c, d_flat.as<uint8_t>(), kHostStream));
+        }
     }
-    if (total) HIPCHK(hcopy(dst, d_stream, total, hipMemcpyDeviceToHost));
+    if (total) HIPCHK(hcopy(dst, d_flat.p, total, hipMemcpyDeviceToHost));
     if (csum) {  // frame.go:117-131; serial walk over the decoded stream
         uint32_t cs = 0;
-        HIPCHK(launch_xxh32_stream(d_stream, total, d_cs.as<uint32_t>(), kHostStream));
+        HIPCHK(launch_xxh32_stream(d_flat.as<uint8_t>(), total, d_cs.as<uint32_t>(), kHostStream));
         HIPCHK(hcopy(&cs, d_cs.p, 4, hipMemcpyDeviceToHost));
         if (cs != want_cs) return fail(LZ4HIP_ERR_FRAME_CHECKSUM, "invalid frame checksum");
     }

@@ -260,6 +260,7 @@ __global__ __launch_bounds__(64) void k_decode2_linked(const uint8_t *__restrict
                                                        const uint64_t *__restrict__ off,
                                                        const uint32_t *__restrict__ sw, size_t nb,
                                                        uint8_t *dst, uint32_t block_cap,
+                                                       size_t dst_cap,
                                                        int32_t *__restrict__ out_len,
                                                        uint64_t *__restrict__ out_off) {
     const int lane = lane_id();
@@ -272,14 +273,18 @@ __global__ __launch_bounds__(64) void k_decode2_linked(const uint8_t *__restrict
             const int n = (int)(w & 0x7FFFFFFFu);
             const uint8_t *in = src + off[b];
             uint8_t *d = dst + total;
+            // never past the stream buffer: the block's room is what is left of it
+            const size_t left = dst_cap - total;
+            const uint32_t cap = left < block_cap ? (uint32_t)left : block_cap;
             if (w >> 31) {
-                r = (uint32_t)n > block_cap ? (int)block_cap : n;
-                wave_copy(d, in, r, lane);
+                r = (uint32_t)n > cap ? (int)cap : n;
+                if ((uint32_t)n > cap && cap < block_cap) r = -1;  // cut by the buffer, not by the block size
+                else wave_copy(d, in, r, lane);
             } else if (n == 0) {
                 r = 0;
             } else {
                 const int prefix = total > (size_t)kWinSize ? kWinSize : (int)total;
-                r = decode2_block(in, n, d, (int)block_cap, prefix, lane);
+                r = decode2_block(in, n, d, (int)cap, prefix, lane);
             }
             r = (int)rfl((uint32_t)r);
             // this wave's stores must be visible to its own later loads
@@ -295,11 +300,11 @@ __global__ __launch_bounds__(64) void k_decode2_linked(const uint8_t *__restrict
 }
 
 hipError_t launch_decode2_linked(const uint8_t *src, const uint64_t *off, const uint32_t *sw,
-                                 size_t nb, uint8_t *dst, uint32_t block_cap, int32_t *out_len,
-                                 uint64_t *out_off, hipStream_t st) {
+                                 size_t nb, uint8_t *dst, uint32_t block_cap, size_t dst_cap,
+                                 int32_t *out_len, uint64_t *out_off, hipStream_t st) {
     if (nb == 0) return hipSuccess;
     hipLaunchKernelGGL(k_decode2_linked, dim3(1), dim3(kWave), 0, st, src, off, sw, nb, dst,
-                       block_cap, out_len, out_off);
+                       block_cap, dst_cap, out_len, out_off);
     return hipGetLastError();
 }
 

@@ -187,15 +187,17 @@ def _decoded_bound(s):
     idx = bd >> 4 & 7
     bs = 1 << (8 + 2 * idx) if idx >= 4 else 0
     bsum = flg >> 4 & 1
-    nb = 0
+    total = 0
     while si + 4 <= n:
         w = int.from_bytes(s[si:si + 4].tobytes(), "little")
         si += 4
         if w == 0:
             break
-        si += (w & 0x7FFFFFFF) + (4 if bsum else 0)
-        nb += 1
-    return nb * bs
+        size = w & 0x7FFFFFFF
+        si += size + (4 if bsum else 0)
+        # a stored block keeps its size, a compressed one grows at most 255-fold
+        total += min(bs, size if w >> 31 else size * 255)
+    return total
 
 
 class Writer:

@@ -172,6 +172,27 @@ def test_ragged_frames(i, oracle):
             lz.frame.uncompress_frame(bytes(bad))
 
 
+def test_many_short_blocks_in_a_4mb_frame(oracle):
+    """A Writer flushed every few bytes: 20,000 blocks of a 4 MiB-block frame.  Device
+    memory must follow the data (a few MB), not n_blocks * block_size (80 GB)."""
+    import struct
+    import lz4_amd as lz
+    hdr = bytes([0x64, 0x70])
+    f = bytearray(struct.pack("<I", 0x184D2204) + hdr + bytes([(oracle.ChecksumZero(hdr) >> 8) & 0xFF]))
+    want = bytearray()
+    for i in range(20000):
+        d = (b"short block %5d " % i) * (1 + i % 5)
+        k, c = oracle.CompressBlock(d, oracle.CompressBlockBound(len(d)))
+        if i % 3 == 0 or k >= len(d):
+            f += struct.pack("<I", len(d) | 0x80000000) + d
+        else:
+            f += struct.pack("<I", k) + c
+        want += d
+    f += struct.pack("<I", 0) + struct.pack("<I", oracle.ChecksumZero(bytes(want)))
+    assert lz.frame.uncompress_frame(bytes(f)) == bytes(want)
+    assert oracle.frame_uncompress(bytes(f), len(want) + 16) == bytes(want)
+
+
 def test_malformed_block_checksum():
     """reader_test.go: malformed.block.lz4 => invalid block checksum."""
     import lz4_amd as lz
