@@ -21,6 +21,7 @@
 #ifndef LZ4_HPP
 #define LZ4_HPP
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <functional>
@@ -153,11 +154,33 @@ struct CompressorHC {
 // ---- options: options.go ----
 class Writer;
 class Reader;
-struct Applier {  // the `applier` interface: exactly one of the two is set
+class CompressingReader;
+struct Applier {  // the `applier` interface: exactly one of the three is set
     Writer *w = nullptr;
     Reader *r = nullptr;
+    CompressingReader *c = nullptr;
 };
 using Option = std::function<Error(Applier)>;
+using BlockDoneHandler = std::function<void(int)>;  // options.go:195-220
+
+namespace detail {
+// One frame for `src` plus, when a handler is set, len(block.Data) of every block.
+inline int64_t frame_compress(const Bytes &src, uint32_t block_size, uint32_t flags, uint32_t level,
+                              uint64_t content_size, Bytes &out, std::vector<uint32_t> *lens) {
+    out.resize(lz4hip_frame_bound(src.size(), block_size, flags));
+    if (!lens)
+        return lz4hip_frame_compress(src.data(), src.size(), block_size, flags, level, content_size,
+                                     out.data(), out.size());
+    const uint32_t bs = (flags & LZ4HIP_F_LEGACY) ? (8u << 20) : (block_size ? block_size : 1);
+    lens->resize(src.size() / bs + 2);
+    size_t nb = 0;
+    const int64_t k = lz4hip_frame_compress_lens(src.data(), src.size(), block_size, flags, level,
+                                                 content_size, out.data(), out.size(), lens->data(),
+                                                 lens->size(), &nb);
+    lens->resize(k < 0 ? 0 : nb);
+    return k;
+}
+}  // namespace detail
 
 // ---- Writer: writer.go ----
 class Writer {
@@ -201,11 +224,18 @@ class Writer {
                          (content_checksum ? LZ4HIP_F_CONTENT_CHECKSUM : 0u) |
                          (content_size > 0 ? LZ4HIP_F_CONTENT_SIZE : 0u) |
                          (readfrom_ ? LZ4HIP_F_READFROM : 0u) | (legacy ? LZ4HIP_F_LEGACY : 0u);
-        Bytes out(lz4hip_frame_bound(buf_.size(), block_size, flags));
-        const int64_t k = lz4hip_frame_compress(buf_.data(), buf_.size(), block_size, flags,
-                                                (uint32_t)level, content_size, out.data(), out.size());
+        Bytes out;
+        std::vector<uint32_t> lens;
+        const int64_t k = detail::frame_compress(buf_, block_size, flags, (uint32_t)level, content_size,
+                                                 out, handler ? &lens : nullptr);
         if (k < 0) return fail(detail::frame_error(k));
         dst_->write(reinterpret_cast<const char *>(out.data()), k);
+        const size_t bs = legacy ? (8u << 20) : block_size;
+        for (size_t i = 0; i < lens.size(); i++) {
+            handler((int)lens[i]);  // writer.go:127
+            if (readfrom_)          // writer.go:234: the bytes read for this block
+                handler((int)(i * bs >= buf_.size() ? 0 : std::min(bs, buf_.size() - i * bs)));
+        }
         state_ = State::Closed;
         return Error::None;
     }
@@ -226,6 +256,7 @@ class Writer {
     CompressionLevel level = Fast;
     int concurrency = 1;
     bool legacy = false;
+    BlockDoneHandler handler;  // OnBlockDoneOption; called in block order once the batch is done
 
   private:
     enum class State { New, Write, Closed, Error };
@@ -260,6 +291,7 @@ class Reader {
         if (e != Error::None) return {0, e};
         const size_t k = len < out_.size() - pos_ ? len : out_.size() - pos_;
         memcpy(buf, out_.data() + pos_, k);
+        report(pos_, pos_ + k);
         pos_ += k;
         return {(int64_t)k, Error::None};
     }
@@ -268,6 +300,7 @@ class Reader {
         const Error e = fill();
         if (e != Error::None) return {0, e};
         const size_t k = out_.size() - pos_;
+        report(pos_, out_.size());
         w.write(reinterpret_cast<const char *>(out_.data() + pos_), (std::streamsize)k);
         pos_ = out_.size();
         return {(int64_t)k, Error::None};
@@ -277,15 +310,27 @@ class Reader {
     void Reset(std::istream &src) {  // reader.go:200-211
         src_ = &src;
         out_.clear();
+        ends_.clear();
         pos_ = 0;
         size_ = 0;
         state_ = State::New;
         err_ = Error::None;
     }
     int concurrency = 1;
+    BlockDoneHandler handler;  // OnBlockDoneOption: decoded bytes per block portion handed out
 
   private:
     enum class State { New, Read, Error };
+    // handler(bn) for every block portion inside [lo, hi) of the stream: reader.go:154,255
+    void report(size_t lo, size_t hi) {
+        if (!handler) return;
+        size_t i = std::upper_bound(ends_.begin(), ends_.end(), lo) - ends_.begin();
+        for (; lo < hi && i < ends_.size(); i++) {
+            const size_t cut = std::min(hi, ends_[i]);
+            handler((int)(cut - lo));
+            lo = cut;
+        }
+    }
     Error fail(Error e) {
         state_ = State::Error;
         err_ = e;
@@ -320,18 +365,93 @@ class Reader {
         if (rc == LZ4HIP_ERR_SHORT) return fail(Error::InvalidFrame);
         if (rc != LZ4HIP_OK) return fail(detail::frame_error(rc));
         out_.resize(decoded_bound(frame, hlen, bs, flags) + 16);
-        const int64_t k = lz4hip_frame_uncompress(frame.data(), frame.size(), out_.data(), out_.size());
+        std::vector<uint32_t> lens(handler ? frame.size() / 4 + 1 : 0);  // >= 4 bytes per block
+        size_t nb = 0;
+        const int64_t k =
+            handler ? lz4hip_frame_uncompress_lens(frame.data(), frame.size(), out_.data(), out_.size(),
+                                                   lens.data(), lens.size(), &nb)
+                    : lz4hip_frame_uncompress(frame.data(), frame.size(), out_.data(), out_.size());
         if (k < 0) return fail(detail::frame_error(k));
         out_.resize((size_t)k);
+        ends_.clear();
+        for (size_t b = 0, at = 0; b < nb; b++) ends_.push_back(at += lens[b]);
         size_ = csize;
         state_ = State::Read;
         return Error::None;
     }
     std::istream *src_;
     Bytes out_;
+    std::vector<size_t> ends_;  // end offset of every block in the decoded stream
     size_t pos_ = 0;
     uint64_t size_ = 0;
     State state_ = State::New;
+    Error err_ = Error::None;
+};
+
+// ---- CompressingReader: compressing_reader.go ----
+// Read() yields the LZ4 frame of everything the source holds (the opposite of Reader).
+// The source is drained and compressed as one batch on the first Read; the bytes are those
+// of init + Compress().Write per block + CloseW (compressing_reader.go:76-81,116-157).
+class CompressingReader {
+  public:
+    explicit CompressingReader(std::istream &src) : src_(&src) {}
+
+    std::istream &Source() { return *src_; }  // compressing_reader.go:46-49
+    Error Close() { return Error::None; }     // :51-56: a std::istream has nothing to close
+    // :58-72: only before the first Read
+    template <class... O> Error Apply(O... options) {
+        if (state_ != State::Initial) return Error::OptionClosedOrError;
+        Error e = Error::None;
+        for (const Option &o : {Option(options)...})
+            if ((e = o(Applier{nullptr, nullptr, this})) != Error::None) return e;
+        return e;
+    }
+    // :83-165.  n == 0 with Error::None is io.EOF.
+    Result Read(uint8_t *p, size_t len) {
+        if (state_ == State::Done) return {0, err_};
+        if (state_ == State::Initial) {
+            const Bytes raw((std::istreambuf_iterator<char>(*src_)), std::istreambuf_iterator<char>());
+            const uint32_t flags = (block_checksum ? LZ4HIP_F_BLOCK_CHECKSUM : 0u) |
+                                   (content_checksum ? LZ4HIP_F_CONTENT_CHECKSUM : 0u) |
+                                   (content_size > 0 ? LZ4HIP_F_CONTENT_SIZE : 0u);
+            std::vector<uint32_t> lens;
+            const int64_t k = detail::frame_compress(raw, block_size, flags, (uint32_t)level,
+                                                     content_size, out_, handler ? &lens : nullptr);
+            if (k < 0) {
+                state_ = State::Done;
+                return {0, err_ = detail::frame_error(k)};
+            }
+            out_.resize((size_t)k);
+            for (uint32_t size : lens) handler((int)size);  // :126,142
+            state_ = State::Reading;
+        }
+        const size_t k = std::min(len, out_.size() - pos_);
+        memcpy(p, out_.data() + pos_, k);
+        pos_ += k;
+        return {(int64_t)k, Error::None};
+    }
+    // :167-174: keeps the options
+    void Reset(std::istream &src) {
+        src_ = &src;
+        out_.clear();
+        pos_ = 0;
+        state_ = State::Initial;
+        err_ = Error::None;
+    }
+
+    uint32_t block_size = Block4Mb;  // DefaultBlockSizeOption
+    bool block_checksum = false;
+    bool content_checksum = true;  // DefaultChecksumOption
+    uint64_t content_size = 0;
+    CompressionLevel level = Fast;
+    BlockDoneHandler handler;
+
+  private:
+    enum class State { Initial, Reading, Done };
+    std::istream *src_;
+    Bytes out_;
+    size_t pos_ = 0;
+    State state_ = State::Initial;
     Error err_ = Error::None;
 };
 
@@ -346,38 +466,50 @@ inline std::pair<bool, Error> ValidFrameHeader(const Bytes &in) {
 }
 
 // ---- the options themselves: options.go:44-242 ----
+namespace detail {
+// the options that options.go gives to both *Writer and *CompressingReader
+template <class F> Error frame_option(Applier a, F set) {
+    if (a.w) return set(*a.w);
+    if (a.c) return set(*a.c);
+    return Error::OptionNotApplicable;
+}
+}  // namespace detail
 inline Option BlockSizeOption(uint32_t size) {
     return [size](Applier a) {
-        if (!a.w) return Error::OptionNotApplicable;
-        if (size != Block64Kb && size != Block256Kb && size != Block1Mb && size != Block4Mb)
-            return Error::OptionInvalidBlockSize;
-        a.w->block_size = size;
-        return Error::None;
+        return detail::frame_option(a, [size](auto &t) {
+            if (size != Block64Kb && size != Block256Kb && size != Block1Mb && size != Block4Mb)
+                return Error::OptionInvalidBlockSize;
+            t.block_size = size;
+            return Error::None;
+        });
     };
 }
 inline Option BlockChecksumOption(bool flag) {
     return [flag](Applier a) {
-        if (!a.w) return Error::OptionNotApplicable;
-        a.w->block_checksum = flag;
-        return Error::None;
+        return detail::frame_option(a, [flag](auto &t) {
+            t.block_checksum = flag;
+            return Error::None;
+        });
     };
 }
 inline Option ChecksumOption(bool flag) {
     return [flag](Applier a) {
-        if (!a.w) return Error::OptionNotApplicable;
-        a.w->content_checksum = flag;
-        return Error::None;
+        return detail::frame_option(a, [flag](auto &t) {
+            t.content_checksum = flag;
+            return Error::None;
+        });
     };
 }
 inline Option SizeOption(uint64_t size) {
     return [size](Applier a) {
-        if (!a.w) return Error::OptionNotApplicable;
-        a.w->content_size = size;
-        return Error::None;
+        return detail::frame_option(a, [size](auto &t) {
+            t.content_size = size;
+            return Error::None;
+        });
     };
 }
 // The GPU path always takes all buffered blocks as one batch, and the Go output does
-// not depend on n either; accepted for both Writer and Reader like the reference.
+// not depend on n either; accepted for Writer and Reader like the reference.
 inline Option ConcurrencyOption(int n) {
     return [n](Applier a) {
         if (a.w) a.w->concurrency = n;
@@ -388,11 +520,23 @@ inline Option ConcurrencyOption(int n) {
 }
 inline Option CompressionLevelOption(uint32_t level) {
     return [level](Applier a) {
-        if (!a.w) return Error::OptionNotApplicable;
-        bool ok = level == Fast;
-        for (uint32_t l = Level1; l <= Level9; l <<= 1) ok = ok || level == l;
-        if (!ok) return Error::OptionInvalidCompressionLevel;
-        a.w->level = (CompressionLevel)level;
+        return detail::frame_option(a, [level](auto &t) {
+            bool ok = level == Fast;
+            for (uint32_t l = Level1; l <= Level9; l <<= 1) ok = ok || level == l;
+            if (!ok) return Error::OptionInvalidCompressionLevel;
+            t.level = (CompressionLevel)level;
+            return Error::None;
+        });
+    };
+}
+// options.go:197-220.  Writer / CompressingReader: len(block.Data) per block (and, from
+// ReadFrom, the bytes read for it); Reader: decoded bytes per block portion handed out.
+inline Option OnBlockDoneOption(BlockDoneHandler handler) {
+    return [handler](Applier a) {
+        if (a.w) a.w->handler = handler;
+        else if (a.r) a.r->handler = handler;
+        else if (a.c) a.c->handler = handler;
+        else return Error::OptionNotApplicable;
         return Error::None;
     };
 }

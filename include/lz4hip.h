@@ -192,12 +192,26 @@ uint32_t lz4hip_xxh32(const uint8_t *p, size_t n);
 int64_t lz4hip_frame_compress(const uint8_t *src, size_t n, uint32_t block_size, uint32_t flags,
                               uint32_t level, uint64_t content_size, uint8_t *dst,
                               size_t dst_cap);
+/* The same call, also reporting len(block.Data) of every block written, in stream order:
+ * the values Writer and CompressingReader hand to an OnBlockDoneOption handler
+ * (writer.go:127, compressing_reader.go:126, options.go:197-220).  Up to max_blocks values
+ * are stored in block_lens (may be NULL); *n_blocks (may be NULL) receives the block count. */
+int64_t lz4hip_frame_compress_lens(const uint8_t *src, size_t n, uint32_t block_size,
+                                   uint32_t flags, uint32_t level, uint64_t content_size,
+                                   uint8_t *dst, size_t dst_cap, uint32_t *block_lens,
+                                   size_t max_blocks, size_t *n_blocks);
 /* io.ReadAll(lz4.NewReader(frame)): reader.go:81-196, lz4stream/block.go:279-340,
  * frame.go:80-131,169-200.  Independent blocks decode as one batch; linked blocks
  * (FLG bit 5 clear) decode in stream order with the output so far as history
  * (reader.go:176-189); legacy frames (magic 0x184C2102) per lz4stream/block.go:284-294.
  * Returns decoded length or a negative LZ4HIP_ERR_*. */
 int64_t lz4hip_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_cap);
+/* The same call, also reporting each block's decoded length in stream order: the values
+ * Reader.WriteTo hands to an OnBlockDoneOption handler (reader.go:255, options.go:197-220).
+ * Up to max_blocks lengths are stored in block_lens (may be NULL); *n_blocks (may be NULL)
+ * receives the number of blocks decoded, which may exceed max_blocks. */
+int64_t lz4hip_frame_uncompress_lens(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_cap,
+                                     uint32_t *block_lens, size_t max_blocks, size_t *n_blocks);
 
 #ifdef __cplusplus
 }

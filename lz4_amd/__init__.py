@@ -3,7 +3,7 @@
 Layout:
   csrc/      hand-written gfx950 HIP kernels + the C ABI (include/lz4hip.h)
   block.py   mirror of lz4.CompressBlock / CompressBlockHC / UncompressBlock
-  frame.py   mirror of lz4.Writer / lz4.Reader (frame path) and its options
+  frame.py   mirror of lz4.Writer / lz4.Reader / lz4.CompressingReader and the options
   device.py  device-resident batched entry points on torch tensors
   corpus.py  seeded synthetic corpora of the benchmark configs
   shard.py   block-range sharding across GPUs (one process per GPU)
@@ -15,6 +15,9 @@ from .block import (Block1Mb, Block4Mb, Block64Kb, Block256Kb, ChecksumZero,  # 
                     Level4, Level5, Level6, Level7, Level8, Level9, UncompressBlock,
                     UncompressBlockWithDict)
 from .frame import (BlockChecksumOption, BlockSizeOption, ChecksumOption,  # noqa: F401
-                    CompressionLevelOption, ConcurrencyOption, ErrInvalidBlockChecksum,
-                    ErrInvalidFrame, ErrInvalidFrameChecksum, ErrInvalidHeaderChecksum,
-                    ErrOptionInvalidBlockSize, LegacyOption, Reader, SizeOption, Writer)
+                    CompressingReader, CompressionLevelOption, ConcurrencyOption,
+                    ErrInvalidBlockChecksum, ErrInvalidFrame, ErrInvalidFrameChecksum,
+                    ErrInvalidHeaderChecksum, ErrOptionClosedOrError,
+                    ErrOptionInvalidBlockSize, ErrOptionInvalidCompressionLevel,
+                    ErrOptionNotApplicable, LegacyOption, OnBlockDoneOption, Reader,
+                    SizeOption, Writer)

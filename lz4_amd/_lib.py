@@ -43,7 +43,9 @@ SYMBOLS = {
     "lz4hip_uncompress_block": (_i64, [_vp, _sz, _vp, _sz, _vp, _sz]),
     "lz4hip_xxh32": (_u32, [_vp, _sz]),
     "lz4hip_frame_compress": (_i64, [_vp, _sz, _u32, _u32, _u32, _u64, _vp, _sz]),
+    "lz4hip_frame_compress_lens": (_i64, [_vp, _sz, _u32, _u32, _u32, _u64, _vp, _sz, _vp, _sz, _vp]),
     "lz4hip_frame_uncompress": (_i64, [_vp, _sz, _vp, _sz]),
+    "lz4hip_frame_uncompress_lens": (_i64, [_vp, _sz, _vp, _sz, _vp, _sz, _vp]),
 }
 
 _lib = None

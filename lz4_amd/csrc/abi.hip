@@ -434,9 +434,9 @@ uint32_t lz4hip_xxh32(const uint8_t *p, size_t n) {
     return out;
 }
 
-int64_t lz4hip_frame_compress(const uint8_t *src, size_t n, uint32_t block_size, uint32_t flags,
-                              uint32_t level, uint64_t content_size, uint8_t *dst,
-                              size_t dst_cap) {
+static int64_t frame_compress(const uint8_t *src, size_t n, uint32_t block_size, uint32_t flags,
+                              uint32_t level, uint64_t content_size, uint8_t *dst, size_t dst_cap,
+                              std::vector<uint32_t> *lens) {
     const bool legacy = flags & LZ4HIP_F_LEGACY;
     if (legacy) block_size = kLegacyBlock;  // frame.go:47-50
     else if (!valid_block_size(block_size)) return fail(LZ4HIP_ERR_BLOCK_SIZE, "invalid block size");
@@ -552,11 +552,41 @@ int64_t lz4hip_frame_compress(const uint8_t *src, size_t n, uint32_t block_size,
                            hipMemcpyDeviceToHost));
         memcpy(dst + end_off, trl, tlen);
         total = (int64_t)(end_off + tlen);
+        if (lens) {  // len(block.Data) of every block = its size word without the raw bit
+            std::vector<uint64_t> off(nb + 1);
+            STEP(hcopy(off.data(), d_off.p, (nb + 1) * 8, hipMemcpyDeviceToHost));
+            for (size_t b = 0; b < nb; b++) {
+                uint32_t w;
+                memcpy(&w, dst + off[b], 4);
+                lens->push_back(w & 0x7FFFFFFFu);
+            }
+            if (legacy && empty_tail) lens->push_back(1);
+        }
 #undef STEP
     } while (0);
     (void)hipStreamDestroy(s_main);
     (void)hipStreamDestroy(s_sum);
     return rc == LZ4HIP_OK ? total : rc;
+}
+
+int64_t lz4hip_frame_compress(const uint8_t *src, size_t n, uint32_t block_size, uint32_t flags,
+                              uint32_t level, uint64_t content_size, uint8_t *dst,
+                              size_t dst_cap) {
+    return frame_compress(src, n, block_size, flags, level, content_size, dst, dst_cap, nullptr);
+}
+
+int64_t lz4hip_frame_compress_lens(const uint8_t *src, size_t n, uint32_t block_size,
+                                   uint32_t flags, uint32_t level, uint64_t content_size,
+                                   uint8_t *dst, size_t dst_cap, uint32_t *block_lens,
+                                   size_t max_blocks, size_t *n_blocks) {
+    std::vector<uint32_t> lens;
+    const int64_t k =
+        frame_compress(src, n, block_size, flags, level, content_size, dst, dst_cap, &lens);
+    if (k < 0) return k;
+    if (n_blocks) *n_blocks = lens.size();
+    if (block_lens && max_blocks)
+        memcpy(block_lens, lens.data(), std::min(max_blocks, lens.size()) * sizeof(uint32_t));
+    return k;
 }
 
 int lz4hip_frame_parse_header(const uint8_t *src, size_t n, uint32_t *block_size, uint32_t *flags,
@@ -626,7 +656,7 @@ int lz4hip_frame_parse_header(const uint8_t *src, size_t n, uint32_t *block_size
 // decoded sizes, so: index every candidate block on the host, decode them all in
 // one batch, then apply the rule in stream order and drop what follows the end.
 static int64_t legacy_uncompress(const uint8_t *src, size_t n, size_t si, uint8_t *dst,
-                                 size_t dst_cap) {
+                                 size_t dst_cap, std::vector<uint32_t> *lens) {
     const uint32_t cap = 8u << 20;
     auto rd32 = [&](size_t at) {
         uint32_t v;
@@ -691,11 +721,13 @@ static int64_t legacy_uncompress(const uint8_t *src, size_t n, size_t si, uint8_
             HIPCHK(hcopy(dst + total, d_out.as<uint8_t>() + b * (size_t)cap, (size_t)len[b],
                              hipMemcpyDeviceToHost));
         total += (size_t)len[b];
+        if (lens) lens->push_back((uint32_t)len[b]);
     }
     return (int64_t)total;
 }
 
-int64_t lz4hip_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_cap) {
+static int64_t frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_cap,
+                                std::vector<uint32_t> *lens) {
     if (!src || (dst_cap && !dst)) return fail(LZ4HIP_ERR_ARG, "null pointer");
     size_t si = 0;
     auto rd32 = [&](size_t at) {
@@ -710,7 +742,7 @@ int64_t lz4hip_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size
         if (rc == LZ4HIP_ERR_SHORT) return fail(LZ4HIP_ERR_FRAME, "truncated frame");
         if (rc != LZ4HIP_OK) return rc;
     }
-    if (hflags & LZ4HIP_F_LEGACY) return legacy_uncompress(src, n, si, dst, dst_cap);
+    if (hflags & LZ4HIP_F_LEGACY) return legacy_uncompress(src, n, si, dst, dst_cap, lens);
     const bool bsum = hflags & LZ4HIP_F_BLOCK_CHECKSUM, csum = hflags & LZ4HIP_F_CONTENT_CHECKSUM,
                independent = !(hflags & LZ4HIP_F_LINKED);
 
@@ -811,6 +843,7 @@ int64_t lz4hip_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size
             foff[i] = total;
             total += (size_t)len[i];
             if (total > dst_cap) return fail(LZ4HIP_ERR_SHORT, "dst_cap too small");
+            if (lens) lens->push_back((uint32_t)len[i]);
         }
         if (independent) {
             HIPCHK(hcopy(d_foff.p, foff.data(), c * 8, hipMemcpyHostToDevice));
@@ -826,6 +859,21 @@ int64_t lz4hip_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size
         if (cs != want_cs) return fail(LZ4HIP_ERR_FRAME_CHECKSUM, "invalid frame checksum");
     }
     return (int64_t)total;
+}
+
+int64_t lz4hip_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_cap) {
+    return frame_uncompress(src, n, dst, dst_cap, nullptr);
+}
+
+int64_t lz4hip_frame_uncompress_lens(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_cap,
+                                     uint32_t *block_lens, size_t max_blocks, size_t *n_blocks) {
+    std::vector<uint32_t> lens;
+    const int64_t k = frame_uncompress(src, n, dst, dst_cap, &lens);
+    if (k < 0) return k;
+    if (n_blocks) *n_blocks = lens.size();
+    if (block_lens && max_blocks)
+        memcpy(block_lens, lens.data(), std::min(max_blocks, lens.size()) * sizeof(uint32_t));
+    return k;
 }
 
 }  // extern "C"

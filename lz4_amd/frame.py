@@ -1,11 +1,14 @@
-"""Host-side mirror of lz4.Writer / lz4.Reader (writer.go, reader.go) and their
-options (options.go) over the C ABI's whole-frame entry points.
+"""Host-side mirror of lz4.Writer / lz4.Reader / lz4.CompressingReader (writer.go,
+reader.go, compressing_reader.go) and their options (options.go) over the C ABI's
+whole-frame entry points.
 
 The Go Writer cuts the stream into blocks and compresses them one at a time (or
 ConcurrencyOption(n) at a time); here the stream is buffered and handed to the
 GPU as ONE batch of independent blocks at Close() -- the output bytes are the
 ones the Go Writer produces (ordering contract of lz4stream/block.go:31-57).
 """
+import ctypes as C
+
 import numpy as np
 
 from . import _lib
@@ -40,6 +43,10 @@ class ErrOptionNotApplicable(Exception):
     """lz4.ErrOptionNotApplicable"""
 
 
+class ErrOptionClosedOrError(Exception):
+    """lz4.ErrOptionClosedOrError"""
+
+
 _FRAME_ERRORS = {
     _lib.ERR_FRAME: ErrInvalidFrame,
     _lib.ERR_HEADER_CHECKSUM: ErrInvalidHeaderChecksum,
@@ -56,7 +63,7 @@ _VALID_LEVELS = (0,) + tuple(1 << k for k in range(9, 18))
 def BlockSizeOption(size):
     """options.go:73-91"""
     def opt(a):
-        if not isinstance(a, Writer):
+        if not isinstance(a, (Writer, CompressingReader)):
             raise ErrOptionNotApplicable()
         if size not in _VALID_BLOCK_SIZES:
             raise ErrOptionInvalidBlockSize()
@@ -67,7 +74,7 @@ def BlockSizeOption(size):
 def BlockChecksumOption(flag):
     """options.go:93-107"""
     def opt(a):
-        if not isinstance(a, Writer):
+        if not isinstance(a, (Writer, CompressingReader)):
             raise ErrOptionNotApplicable()
         a.block_checksum = bool(flag)
     return opt
@@ -76,7 +83,7 @@ def BlockChecksumOption(flag):
 def ChecksumOption(flag):
     """options.go:109-123 (content checksum; default on)"""
     def opt(a):
-        if not isinstance(a, Writer):
+        if not isinstance(a, (Writer, CompressingReader)):
             raise ErrOptionNotApplicable()
         a.content_checksum = bool(flag)
     return opt
@@ -85,7 +92,7 @@ def ChecksumOption(flag):
 def SizeOption(size):
     """options.go:125-141: content size in the header when > 0"""
     def opt(a):
-        if not isinstance(a, Writer):
+        if not isinstance(a, (Writer, CompressingReader)):
             raise ErrOptionNotApplicable()
         a.content_size = int(size)
     return opt
@@ -96,14 +103,36 @@ def ConcurrencyOption(n):
     processes all buffered blocks as one batch, and the Go output does not
     depend on n either."""
     def opt(a):
+        if not isinstance(a, (Writer, Reader)):
+            raise ErrOptionNotApplicable()
         a.concurrency = n
     return opt
+
+
+def OnBlockDoneOption(handler):
+    """options.go:197-220: handler(size) per processed block.  Writer and
+    CompressingReader report each block's stored payload length (writer.go:127,
+    compressing_reader.go:126), Writer.ReadFrom also the bytes read for it
+    (writer.go:234); Reader reports decoded bytes (reader.go:154,255).  The blocks are
+    processed as one batch here, so the calls come in block order once the batch is done."""
+    if handler is None:
+        handler = _on_block_done
+
+    def opt(a):
+        if not isinstance(a, (Writer, Reader, CompressingReader)):
+            raise ErrOptionNotApplicable()
+        a.handler = handler
+    return opt
+
+
+def _on_block_done(size):
+    """options.go:195"""
 
 
 def CompressionLevelOption(level):
     """options.go:167-195"""
     def opt(a):
-        if not isinstance(a, Writer):
+        if not isinstance(a, (Writer, CompressingReader)):
             raise ErrOptionNotApplicable()
         if level not in _VALID_LEVELS:
             raise ErrOptionInvalidCompressionLevel()
@@ -127,9 +156,10 @@ def _ro(b):
 
 
 def compress_frame(data, block_size=1 << 22, block_checksum=False, content_checksum=True,
-                   content_size=0, level=Fast, readfrom=False, legacy=False):
+                   content_size=0, level=Fast, readfrom=False, legacy=False, block_lens=None):
     """One frame for `data`: Writer.Write(data); Writer.Close()  (or io.Copy when
-    readfrom=True: writer.go:199-242)."""
+    readfrom=True: writer.go:199-242).  A list passed as block_lens receives the stored
+    payload length of every block written."""
     _lib.require_gpu()
     lib = _lib.load()
     s = _ro(data)
@@ -140,15 +170,26 @@ def compress_frame(data, block_size=1 << 22, block_checksum=False, content_check
              | (_lib.F_LEGACY if legacy else 0))
     cap = lib.lz4hip_frame_bound(s.size, block_size, flags)
     d = np.empty(cap, dtype=np.uint8)
-    k = lib.lz4hip_frame_compress(s.ctypes.data if s.size else None, s.size, block_size, flags,
-                                  level, content_size, d.ctypes.data, cap)
+    if block_lens is None:
+        k = lib.lz4hip_frame_compress(s.ctypes.data if s.size else None, s.size, block_size, flags,
+                                      level, content_size, d.ctypes.data, cap)
+    else:
+        max_blocks = s.size // (8 << 20 if legacy else block_size) + 2
+        lens = np.empty(max_blocks, dtype=np.uint32)
+        nb = C.c_size_t(0)
+        k = lib.lz4hip_frame_compress_lens(s.ctypes.data if s.size else None, s.size, block_size,
+                                           flags, level, content_size, d.ctypes.data, cap,
+                                           lens.ctypes.data, max_blocks, C.addressof(nb))
+        if k >= 0:
+            block_lens.extend(int(x) for x in lens[:nb.value])
     if k < 0:
         raise _FRAME_ERRORS.get(k, _lib.Lz4HipError)(*(() if k in _FRAME_ERRORS else (k, _lib.last_error())))
     return d[:k].tobytes()
 
 
-def uncompress_frame(frame, size_hint=None):
-    """io.ReadAll(lz4.NewReader(frame))."""
+def uncompress_frame(frame, size_hint=None, block_lens=None):
+    """io.ReadAll(lz4.NewReader(frame)).  A list passed as block_lens receives each
+    block's decoded length in stream order."""
     _lib.require_gpu()
     lib = _lib.load()
     s = _ro(frame)
@@ -156,7 +197,16 @@ def uncompress_frame(frame, size_hint=None):
     # block size; count size words cheaply from the descriptor when no hint is given.
     cap = size_hint if size_hint is not None else _decoded_bound(s)
     d = np.empty(max(cap, 1), dtype=np.uint8)
-    k = lib.lz4hip_frame_uncompress(s.ctypes.data if s.size else None, s.size, d.ctypes.data, cap)
+    if block_lens is None:
+        k = lib.lz4hip_frame_uncompress(s.ctypes.data if s.size else None, s.size, d.ctypes.data, cap)
+    else:
+        max_blocks = s.size // 4 + 1    # every block costs at least its size word
+        lens = np.empty(max_blocks, dtype=np.uint32)
+        nb = C.c_size_t(0)
+        k = lib.lz4hip_frame_uncompress_lens(s.ctypes.data if s.size else None, s.size, d.ctypes.data,
+                                             cap, lens.ctypes.data, max_blocks, C.addressof(nb))
+        if k >= 0:
+            block_lens.extend(int(x) for x in lens[:nb.value])
     if k < 0:
         if k in _FRAME_ERRORS:
             raise _FRAME_ERRORS[k](_lib.last_error())
@@ -212,6 +262,7 @@ class Writer:
         self.level = Fast
         self.concurrency = 1
         self.legacy = False
+        self.handler = _on_block_done
         self._buf = bytearray()
         self._readfrom = False
         self._closed = False
@@ -235,9 +286,15 @@ class Writer:
         if self._closed:
             return
         self._closed = True
+        lens = []
         self._w.write(compress_frame(self._buf, self.block_size, self.block_checksum,
                                      self.content_checksum, self.content_size, self.level,
-                                     self._readfrom, self.legacy))
+                                     self._readfrom, self.legacy, lens))
+        bs = (8 << 20) if self.legacy else self.block_size
+        for i, size in enumerate(lens):
+            self.handler(size)                                           # writer.go:127
+            if self._readfrom:                                           # writer.go:234
+                self.handler(max(0, min(bs, len(self._buf) - i * bs)))
 
     def Reset(self, w):
         self._w = w
@@ -254,6 +311,8 @@ class Reader:
         self._out = None
         self._pos = 0
         self.concurrency = 1
+        self.handler = _on_block_done
+        self._ends = []     # end offset of every block in the decoded stream
 
     def Apply(self, *options):
         for o in options:
@@ -261,10 +320,94 @@ class Reader:
 
     def _fill(self):
         if self._out is None:
-            self._out = uncompress_frame(self._r.read())
+            lens = []
+            self._out = uncompress_frame(self._r.read(), block_lens=lens)
+            self._ends, at = [], 0
+            for k in lens:
+                at += k
+                self._ends.append(at)
+
+    def _report(self, lo, hi):
+        """handler(bn) for every block portion in [lo, hi) of the stream: reader.go:154,255."""
+        if self.handler is _on_block_done:
+            return
+        import bisect
+        i = bisect.bisect_right(self._ends, lo)
+        while lo < hi and i < len(self._ends):
+            cut = min(hi, self._ends[i])
+            self.handler(cut - lo)
+            lo = cut
+            i += 1
 
     def Read(self, n=-1):
         self._fill()
+        if n < 0:
+            n = len(self._out) - self._pos
+        b = self._out[self._pos:self._pos + n]
+        self._report(self._pos, self._pos + len(b))
+        self._pos += len(b)
+        return b
+
+    read = Read
+
+    def WriteTo(self, w):
+        self._fill()
+        self._report(self._pos, len(self._out))
+        w.write(self._out[self._pos:])
+        k = len(self._out) - self._pos
+        self._pos = len(self._out)
+        return k
+
+    def Reset(self, r):
+        self._r = r
+        self._out = None
+        self._pos = 0
+        self._ends = []
+
+
+class CompressingReader:
+    """lz4.CompressingReader (compressing_reader.go:21-174): Read() yields the LZ4 frame
+    of everything the source holds -- the opposite of Reader.  The source is drained and
+    compressed as one batch on the first Read; the frame bytes are those of
+    Writer.Write(all) + Close() (init / Compress().Write / CloseW: :76-81,116-157)."""
+
+    def __init__(self, src):
+        self.block_size = 1 << 22       # DefaultBlockSizeOption
+        self.block_checksum = False
+        self.content_checksum = True    # DefaultChecksumOption
+        self.content_size = 0
+        self.level = Fast
+        self.handler = _on_block_done
+        self.Reset(src)
+
+    def Source(self):
+        """compressing_reader.go:46-49"""
+        return self._src
+
+    def Close(self):
+        """compressing_reader.go:51-56: closes the source"""
+        close = getattr(self._src, "close", None)
+        if close is not None:
+            close()
+
+    close = Close
+
+    def Apply(self, *options):
+        """compressing_reader.go:58-72: only before the first Read"""
+        if self._out is not None:
+            raise ErrOptionClosedOrError()
+        for o in options:
+            o(self)
+
+    def Read(self, n=-1):
+        """compressing_reader.go:83-165; b"" is io.EOF"""
+        if self._out is None:
+            lens = []
+            self._out = compress_frame(self._src.read(), self.block_size, self.block_checksum,
+                                       self.content_checksum, self.content_size, self.level,
+                                       block_lens=lens)
+            for size in lens:
+                self.handler(size)      # :126,142
         if n < 0:
             n = len(self._out) - self._pos
         b = self._out[self._pos:self._pos + n]
@@ -273,14 +416,8 @@ class Reader:
 
     read = Read
 
-    def WriteTo(self, w):
-        self._fill()
-        w.write(self._out[self._pos:])
-        k = len(self._out) - self._pos
-        self._pos = len(self._out)
-        return k
-
-    def Reset(self, r):
-        self._r = r
+    def Reset(self, src):
+        """compressing_reader.go:167-174: keeps the options"""
+        self._src = src
         self._out = None
         self._pos = 0

@@ -147,7 +147,7 @@ static Bytes oracle_frame(const Bytes &src, uint32_t bs, uint32_t flags, uint32_
 }
 static void TestWriter() {
     const char *files[] = {"empty.txt", "e.txt", "gettysburg.txt", "Mark.Twain-Tom.Sawyer.txt",
-                           "pg1661.txt", "pi.txt", "random.data", "repeat.txt"};
+                           "pg1661.txt", "pi.txt", "random.data", "repeat.txt", "issue102.data"};
     struct Opt { const char *name; lz4::Option o; uint32_t flags_on, flags_off, bs, level; uint64_t csize; };
     const Opt opts[] = {
         {"ConcurrencyOption(1)", lz4::ConcurrencyOption(1), 0, 0, 0, 0, 0},
@@ -255,6 +255,112 @@ static void TestLegacy() {
     CHECK(zr.WriteTo(back).err == Error::None && back.str() == std::string(raw.begin(), raw.end()));
 }
 
+// --- compressing_reader_test.go:13-78 ---
+static void TestCompressingReader() {
+    const char *files[] = {"e.txt", "gettysburg.txt", "Mark.Twain-Tom.Sawyer.txt", "pg1661.txt",
+                           "pi.txt", "random.data", "repeat.txt", "issue102.data"};
+    for (const char *name : files) {
+        const Bytes raw = load(name);
+        for (int size_opt = 0; size_opt < 2; size_opt++) {
+            std::istringstream in(std::string(raw.begin(), raw.end()));
+            lz4::CompressingReader zcomp(in);
+            CHECK(zcomp.Apply(size_opt ? lz4::SizeOption(123) : lz4::BlockChecksumOption(true),
+                              lz4::CompressionLevelOption(lz4::Level1)) == Error::None);
+            Bytes zout;
+            uint8_t buf[8192];
+            for (;;) {
+                const lz4::Result r = zcomp.Read(buf, sizeof buf);
+                CHECK(r.err == Error::None);
+                if (r.n == 0) break;
+                zout.insert(zout.end(), buf, buf + r.n);
+            }
+            const Bytes want = oracle_frame(raw, lz4::Block4Mb,
+                                            LZ4O_F_CONTENT_CHECKSUM | (size_opt ? LZ4O_F_CONTENT_SIZE : LZ4O_F_BLOCK_CHECKSUM),
+                                            lz4::Level1, size_opt ? 123 : 0);
+            CHECK(zout == want);
+            std::istringstream zin(std::string(zout.begin(), zout.end()));
+            lz4::Reader zr(zin);
+            std::ostringstream back;
+            const lz4::Result r = zr.WriteTo(back);
+            CHECK(r.err == Error::None && (size_t)r.n == raw.size());
+            CHECK(back.str() == std::string(raw.begin(), raw.end()));
+            if (size_opt) CHECK(zr.Size() == 123);
+            CHECK(zcomp.Apply(lz4::ChecksumOption(false)) == Error::OptionClosedOrError);
+        }
+    }
+    std::istringstream none;
+    lz4::CompressingReader zc(none);
+    CHECK(zc.Apply(lz4::ConcurrencyOption(2)) == Error::OptionNotApplicable);
+    CHECK(zc.Apply(lz4::LegacyOption(true)) == Error::OptionNotApplicable);
+}
+
+// --- options.go:197-220 (OnBlockDoneOption) ---
+static void TestOnBlockDone() {
+    const Bytes raw = load("pg1661.txt");  // 9 x 64 KiB + 5,109 bytes
+    const size_t bs = lz4::Block64Kb;
+    std::vector<int> want, sizes;
+    for (size_t at = 0; at < raw.size(); at += bs) {
+        const size_t len = std::min(bs, raw.size() - at);
+        Bytes dst(len);
+        const int64_t n = lz4o_compress_fast(raw.data() + at, len, dst.data(), len);
+        want.push_back(n > 0 ? (int)n : (int)len);  // lz4stream/block.go:224-252
+        sizes.push_back((int)len);
+    }
+    std::vector<int> seen;
+    const auto note = [&seen](int n) { seen.push_back(n); };
+    std::ostringstream zout;
+    lz4::Writer zw(zout);
+    CHECK(zw.Apply(lz4::BlockSizeOption(lz4::Block64Kb), lz4::OnBlockDoneOption(note)) == Error::None);
+    zw.Write(raw);
+    CHECK(zw.Close() == Error::None);
+    CHECK(seen == want);
+
+    seen.clear();
+    std::ostringstream zout2;
+    lz4::Writer zw2(zout2);
+    CHECK(zw2.Apply(lz4::BlockSizeOption(lz4::Block64Kb), lz4::OnBlockDoneOption(note)) == Error::None);
+    std::istringstream in(std::string(raw.begin(), raw.end()));
+    zw2.ReadFrom(in);
+    CHECK(zw2.Close() == Error::None);
+    std::vector<int> both;
+    for (size_t i = 0; i < want.size(); i++) {
+        both.push_back(want[i]);
+        both.push_back(sizes[i]);
+    }
+    CHECK(seen == both);
+
+    seen.clear();
+    std::istringstream in2(std::string(raw.begin(), raw.end()));
+    lz4::CompressingReader zc(in2);
+    CHECK(zc.Apply(lz4::BlockSizeOption(lz4::Block64Kb), lz4::OnBlockDoneOption(note)) == Error::None);
+    Bytes all(zout.str().size() + 16);
+    CHECK((size_t)zc.Read(all.data(), all.size()).n == zout.str().size());
+    CHECK(seen == want);
+
+    seen.clear();
+    std::istringstream zin(zout.str());
+    lz4::Reader zr(zin);
+    CHECK(zr.Apply(lz4::OnBlockDoneOption(note)) == Error::None);
+    std::ostringstream back;
+    CHECK((size_t)zr.WriteTo(back).n == raw.size());
+    CHECK(seen == sizes);
+
+    seen.clear();
+    std::istringstream zin2(zout.str());
+    lz4::Reader zr2(zin2);
+    CHECK(zr2.Apply(lz4::OnBlockDoneOption(note)) == Error::None);
+    Bytes buf(100000);  // straddles block ends: every portion is reported
+    size_t total = 0;
+    for (;;) {
+        const lz4::Result r = zr2.Read(buf.data(), buf.size());
+        if (r.n == 0) break;
+        total += (size_t)r.n;
+    }
+    long sum = 0;
+    for (int n : seen) sum += n;
+    CHECK(total == raw.size() && (size_t)sum == raw.size());
+}
+
 // --- options.go / writer.go:43-59 / reader.go:49-64,265-275 ---
 static void TestOptionsAndHeader() {
     std::ostringstream sink;
@@ -306,6 +412,8 @@ int main(int argc, char **argv) {
     TestWriter();
     TestReader();
     TestLegacy();
+    TestCompressingReader();
+    TestOnBlockDone();
     TestOptionsAndHeader();
     printf("host_test: %d checks, %d failed\n", g_checks, g_fail);
     return g_fail ? 1 : 0;

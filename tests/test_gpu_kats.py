@@ -215,7 +215,7 @@ def test_bad_header_checksum_and_magic():
 
 
 @pytest.mark.parametrize("name", ["pg1661.txt", "random.data", "repeat.txt", "empty.txt",
-                                  "bzImage_lz4_isolated"])
+                                  "bzImage_lz4_isolated", "issue102.data"])
 @pytest.mark.parametrize("opts", [dict(), dict(block_checksum=True), dict(content_size=123),
                                   dict(block_size=1 << 16, block_checksum=True),
                                   dict(block_size=1 << 18, content_checksum=False),
@@ -225,7 +225,7 @@ def test_writer_frames_byte_identical_to_oracle(name, opts, oracle):
     """TestWriter (writer_test.go:19-92) option matrix; compares the frame BYTES
     with the oracle's Writer restatement, then reads it back."""
     import lz4_amd as lz
-    if name == "bzImage_lz4_isolated" and opts.get("level"):
+    if name in ("bzImage_lz4_isolated", "issue102.data") and opts.get("level"):
         pytest.skip("HC on 1 MB binary is covered by test_gpu_batch at test size")
     data = load(name)
     w = io.BytesIO()
@@ -256,3 +256,101 @@ def test_flush_header_is_7_bytes():
     zw.Close()
     assert len(w.getvalue()) == 7 + 4 + 4  # header + end mark + content checksum
     assert w.getvalue()[7:] == b"\x00\x00\x00\x00\x05\x5d\xcc\x02"
+
+
+CR_FILES = ["e.txt", "gettysburg.txt", "Mark.Twain-Tom.Sawyer.txt", "pg1661.txt", "pi.txt",
+            "random.data", "repeat.txt", "issue102.data"]
+
+
+@pytest.mark.parametrize("name", CR_FILES)
+@pytest.mark.parametrize("option", ["BlockChecksumOption(true)", "SizeOption(123)"])
+def test_compressing_reader(name, option, oracle):
+    """TestCompressingReader (compressing_reader_test.go:13-78): read the frame out of a
+    CompressingReader at Level1, decode it with Reader, compare; with SizeOption(123) the
+    Reader reports Size() 123.  Also: the bytes are the oracle's Writer bytes."""
+    import lz4_amd as lz
+    raw = load(name)
+    zcomp = lz.CompressingReader(io.BytesIO(raw))
+    opt = lz.BlockChecksumOption(True) if option.startswith("Block") else lz.SizeOption(123)
+    zcomp.Apply(opt, lz.CompressionLevelOption(lz.Level1))
+    zout = bytearray()
+    while True:                       # ioutil.ReadAll: growing reads
+        b = zcomp.Read(4096 + len(zout))
+        if not b:
+            break
+        zout += b
+    flags = 2 | (1 if option.startswith("Block") else 4)
+    assert bytes(zout) == oracle.frame_compress(raw, 1 << 22, flags, lz.Level1,
+                                                0 if option.startswith("Block") else 123)
+    zr = lz.Reader(io.BytesIO(bytes(zout)))
+    assert zr.Read() == raw
+    with pytest.raises(lz.ErrOptionClosedOrError):
+        zcomp.Apply(lz.ChecksumOption(False))      # compressing_reader.go:60-62
+    with pytest.raises(lz.ErrOptionNotApplicable):
+        lz.CompressingReader(io.BytesIO(b"")).Apply(lz.ConcurrencyOption(2))   # options.go:136-147
+    zcomp.Reset(io.BytesIO(b"abc"))                 # keeps the options
+    again = zcomp.Read()
+    assert lz.Reader(io.BytesIO(again)).Read() == b"abc"
+    assert again[4] == zout[4] and again[5] == zout[5]   # same FLG / BD
+
+
+def test_on_block_done_handlers(oracle):
+    """OnBlockDoneOption (options.go:197-220): Writer and CompressingReader report
+    len(block.Data) of every block (writer.go:127), ReadFrom also the bytes read for it
+    (writer.go:234); Reader.WriteTo the decoded length of every block (reader.go:255)."""
+    import lz4_amd as lz
+    raw = load("pg1661.txt")           # 594,933 B = 9 x 64 KiB + 5,109
+    bs = 1 << 16
+    blocks = [raw[i:i + bs] for i in range(0, len(raw), bs)]
+    want = []
+    for b in blocks:                   # FrameDataBlock.Compress: dst = len(src); 0 => stored raw
+        n = oracle.CompressBlock(b, len(b))[0]
+        want.append(n if n > 0 else len(b))
+    seen = []
+    w = io.BytesIO()
+    zw = lz.Writer(w)
+    zw.Apply(lz.BlockSizeOption(bs), lz.OnBlockDoneOption(seen.append))
+    zw.Write(raw)
+    zw.Close()
+    assert seen == want
+    seen2 = []
+    zw = lz.Writer(io.BytesIO())
+    zw.Apply(lz.BlockSizeOption(bs), lz.OnBlockDoneOption(seen2.append))
+    zw.ReadFrom(io.BytesIO(raw))
+    zw.Close()
+    assert seen2 == [x for pair in zip(want, map(len, blocks)) for x in pair]
+    seen3 = []
+    zc = lz.CompressingReader(io.BytesIO(raw))
+    zc.Apply(lz.BlockSizeOption(bs), lz.OnBlockDoneOption(seen3.append))
+    assert zc.Read() == w.getvalue() and seen3 == want
+    got = []
+    zr = lz.Reader(io.BytesIO(w.getvalue()))
+    zr.Apply(lz.OnBlockDoneOption(got.append))
+    sink = io.BytesIO()
+    assert zr.WriteTo(sink) == len(raw) and sink.getvalue() == raw
+    assert got == [len(b) for b in blocks]
+    got = []
+    zr = lz.Reader(io.BytesIO(w.getvalue()))
+    zr.Apply(lz.OnBlockDoneOption(got.append))
+    out = bytearray()
+    while True:
+        b = zr.Read(100000)            # straddles block ends: portions are reported
+        if not b:
+            break
+        out += b
+    assert bytes(out) == raw and sum(got) == len(raw) and max(got) <= bs
+    # a stream that is a block multiple read through ReadFrom ends in an empty block (T9)
+    seen4 = []
+    zw = lz.Writer(io.BytesIO())
+    zw.Apply(lz.BlockSizeOption(bs), lz.OnBlockDoneOption(seen4.append))
+    zw.ReadFrom(io.BytesIO(raw[:2 * bs]))
+    zw.Close()
+    assert seen4 == [want[0], bs, want[1], bs, 0, 0]
+    # legacy frames: 8 MiB blocks, len(block.Data) again
+    seen5 = []
+    lw = io.BytesIO()
+    zw = lz.Writer(lw)
+    zw.Apply(lz.LegacyOption(True), lz.OnBlockDoneOption(seen5.append))
+    zw.Write(raw)
+    zw.Close()
+    assert seen5 == [len(lw.getvalue()) - 8]
