@@ -121,6 +121,9 @@ hipError_t launch_decode_any(const uint8_t *src, const uint64_t *off, const uint
 // threads (cgo runs each goroutine's call on its own thread) then overlap on the GPU
 // instead of queueing behind each other.  hcopy = a blocking copy on that stream.
 const hipStream_t kHostStream = hipStreamPerThread;
+// Piece size of the source upload in lz4hip_frame_compress: a multiple of every block
+// size (the legacy 8 MiB included) and of XXH32's 16-byte stripe.
+constexpr size_t kUploadPiece = 64u << 20;
 hipError_t hcopy(void *dst, const void *src, size_t n, hipMemcpyKind kind) {
     hipError_t e = hipMemcpyAsync(dst, src, n, kind, kHostStream);
     if (e != hipSuccess) return e;
@@ -138,6 +141,19 @@ struct DevBuf {
         if (p) (void)hipFreeAsync(p, kHostStream);
     }
     template <class T> T *as() { return static_cast<T *>(p); }
+};
+
+// A second, non-blocking stream owned by one call (the content-checksum walk).  The
+// destructor waits for it, so buffers declared BEFORE it outlive everything queued on it.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipError_t create() { return hipStreamCreateWithFlags(&s, hipStreamNonBlocking); }
+    ~SideStream() {
+        if (s) {
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamDestroy(s);
+        }
+    }
 };
 
 }  // namespace
@@ -466,9 +482,10 @@ static int64_t frame_compress(const uint8_t *src, size_t n, uint32_t block_size,
         hlen = lz4hip_frame_header(hdr, block_size, flags, content_size);
     }
 
-    DevBuf d_src, d_comp, d_res, d_xxh, d_off, d_frame, d_cs, d_fws;
+    DevBuf d_src, d_comp, d_res, d_xxh, d_off, d_frame, d_cs, d_state, d_fws;
     hipStream_t s_main = nullptr, s_sum = nullptr;
     HIPCHK(d_src.alloc(n + 16));
+    HIPCHK(d_state.alloc(6 * sizeof(uint32_t)));
     HIPCHK(d_comp.alloc(nb_data * (size_t)block_size));
     HIPCHK(d_res.alloc((nb + 1) * sizeof(int32_t)));
     HIPCHK(d_xxh.alloc((nb + 1) * sizeof(uint32_t)));
@@ -489,10 +506,24 @@ static int64_t frame_compress(const uint8_t *src, size_t n, uint32_t block_size,
             break;                        \
         }                                 \
     }
-        if (n) STEP(hcopy(d_src.p, src, n, hipMemcpyHostToDevice));
+        // The content checksum is one serial walk (about 2.4 GB/s) and bounds the call, so it
+        // starts as early as it can: the source goes up in pieces and the chained checksum
+        // (XXHZero.Write per piece, xxh32zero.go:58-86) follows each piece on its own stream
+        // while the next one is still on the bus and while the blocks compress.
+        {
+            hipError_t e = hipSuccess;
+            size_t at = 0;
+            do {
+                const size_t len = std::min(kUploadPiece, n - at);
+                if (len) e = hcopy(d_src.as<uint8_t>() + at, src + at, len, hipMemcpyHostToDevice);
+                if (e == hipSuccess && csum)
+                    e = launch_xxh32_update(d_src.as<uint8_t>() + at, len, d_state.as<uint32_t>(),
+                                            at == 0, at + len >= n, d_cs.as<uint32_t>(), s_sum);
+                at += len;
+            } while (e == hipSuccess && at < n);
+            STEP(e);
+        }
         STEP(hipMemsetAsync(d_res.p, 0, (nb + 1) * sizeof(int32_t), s_main));
-        // content checksum: serial walk, overlapped on its own stream
-        if (csum) STEP(launch_xxh32_stream(d_src.as<uint8_t>(), n, d_cs.as<uint32_t>(), s_sum));
         if (nb_data) {
             if (level == 0) {
                 const size_t wsb = lz4hip_fast_workspace_bytes(nb_data);
@@ -523,6 +554,14 @@ static int64_t frame_compress(const uint8_t *src, size_t n, uint32_t block_size,
         uint64_t end_off = 0;
         STEP(hipMemcpyAsync(&end_off, d_off.as<uint64_t>() + nb, 8, hipMemcpyDeviceToHost, s_main));
         STEP(hipStreamSynchronize(s_main));
+        if (end_off > dst_cap) {
+            rc = fail(LZ4HIP_ERR_SHORT, "frame larger than dst_cap");
+            break;
+        }
+        memcpy(dst, hdr, hlen);  // the blocks go down while the checksum walk finishes
+        if (end_off > hlen)
+            STEP(hcopy(dst + hlen, d_frame.as<uint8_t>() + hlen, end_off - hlen,
+                           hipMemcpyDeviceToHost));
         STEP(hipStreamSynchronize(s_sum));
         uint32_t cs = 0;
         if (csum) STEP(hcopy(&cs, d_cs.p, 4, hipMemcpyDeviceToHost));
@@ -546,10 +585,6 @@ static int64_t frame_compress(const uint8_t *src, size_t n, uint32_t block_size,
             rc = fail(LZ4HIP_ERR_SHORT, "frame larger than dst_cap");
             break;
         }
-        memcpy(dst, hdr, hlen);
-        if (end_off > hlen)
-            STEP(hcopy(dst + hlen, d_frame.as<uint8_t>() + hlen, end_off - hlen,
-                           hipMemcpyDeviceToHost));
         memcpy(dst + end_off, trl, tlen);
         total = (int64_t)(end_off + tlen);
         if (lens) {  // len(block.Data) of every block = its size word without the raw bit
@@ -784,7 +819,7 @@ static int64_t frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size
     // slots and are packed into the contiguous stream; linked blocks decode straight
     // into it.  Errors keep stream order (lz4stream/block.go:187-194): chunks run in
     // order and each chunk is checked front to back before the next starts.
-    DevBuf d_src, d_off, d_sw, d_slots, d_flat, d_len, d_xxh, d_cs, d_foff;
+    DevBuf d_src, d_off, d_sw, d_slots, d_flat, d_len, d_xxh, d_cs, d_foff, d_state;
     // stream buffer: no more than the blocks can decode to (a compressed block grows at
     // most 255-fold, a stored one not at all), no more than the caller can take, plus one
     // block of slack so that only the final check decides "dst_cap too small"
@@ -811,7 +846,14 @@ static int64_t frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size
     std::vector<int32_t> len(chunk);
     std::vector<uint32_t> got(chunk);
     std::vector<uint64_t> foff(chunk);
-    size_t total = 0;
+    size_t total = 0, hashed = 0;
+    bool started = false;
+    SideStream sum;  // declared after the buffers: synchronised and destroyed before they are freed
+    if (csum) {
+        HIPCHK(d_state.alloc(6 * sizeof(uint32_t)));
+        HIPCHK(hipStreamSynchronize(kHostStream));  // the allocations are ordered on it
+        HIPCHK(sum.create());
+    }
     for (size_t b0 = 0; b0 < nb; b0 += chunk) {
         const size_t c = std::min(chunk, nb - b0);
         if (independent) {
@@ -850,11 +892,27 @@ static int64_t frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size
             HIPCHK(launch_pack_blocks(d_slots.as<uint8_t>(), bs, d_len.as<int32_t>(),
                                       d_foff.as<uint64_t>(), c, d_flat.as<uint8_t>(), kHostStream));
         }
+        // frame.go:117-131: the content checksum is one serial walk over the decoded stream
+        // and bounds the call, so it follows the chunks on its own stream (XXHZero.Write per
+        // piece; pieces before the last are cut to the 16-byte stripe) while the next chunk
+        // decodes and while the output goes down to the host.
+        if (csum) {
+            const bool last = b0 + c >= nb;
+            const size_t upto = last ? total : total & ~(size_t)15;
+            if (last || upto > hashed) {
+                HIPCHK(hipStreamSynchronize(kHostStream));  // chunk packed
+                HIPCHK(launch_xxh32_update(d_flat.as<uint8_t>() + hashed, upto - hashed,
+                                           d_state.as<uint32_t>(), !started, last,
+                                           d_cs.as<uint32_t>(), sum.s));
+                hashed = upto;
+                started = true;
+            }
+        }
     }
     if (total) HIPCHK(hcopy(dst, d_flat.p, total, hipMemcpyDeviceToHost));
-    if (csum) {  // frame.go:117-131; serial walk over the decoded stream
+    if (csum) {
         uint32_t cs = 0;
-        HIPCHK(launch_xxh32_stream(d_flat.as<uint8_t>(), total, d_cs.as<uint32_t>(), kHostStream));
+        HIPCHK(hipStreamSynchronize(sum.s));
         HIPCHK(hcopy(&cs, d_cs.p, 4, hipMemcpyDeviceToHost));
         if (cs != want_cs) return fail(LZ4HIP_ERR_FRAME_CHECKSUM, "invalid frame checksum");
     }

@@ -98,49 +98,73 @@ __global__ __launch_bounds__(64) void k_xxh32_blocks(const uint8_t *__restrict__
 //
 // Each accumulator is the chain v <- rol(v + x*P2, 13) * P1 over every 4th word of the
 // stream (xxh32zero.go:66-86); rotation makes it non-linear, so the chain cannot be
-// split or prefix-summed.  What can be taken off the chain is everything else: a wave
-// loads 64 stripes (1 KiB) with one coalesced load, all lanes multiply their words by
-// P2 in parallel and publish them transposed in LDS, and lanes 0..3 -- one accumulator
-// each -- run the 64-step add/rotate/multiply chain from LDS while the next chunk's
-// loads are already in flight.  The chain is then the only serial cost: about 25
-// cycles per 16-byte stripe.
-__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// split or prefix-summed.  What can be taken off the chain is everything else, and it is
+// taken off the chain's WAVE too: a lone wave issues one instruction every few cycles, so
+// every load, multiply and LDS store it does itself is time the chain stands still.
+// A block of four waves: waves 1..3 are producers -- each loads a 4 KiB chunk (256
+// stripes) with coalesced 16-byte loads three chunks ahead, multiplies its words by P2
+// and publishes them in LDS, one row per accumulator; wave 0's lanes 0..3 -- one
+// accumulator each -- do nothing but read their row and run add / rotate / multiply.
+// Two LDS buffers, one barrier per chunk.  tools/micro/xxhchain.hip measures the bare
+// chain at 15.4 cycles per 16-byte stripe (2.5 GB/s); that is the bound of this kernel.
+constexpr int kXBlock = 256;                   // threads: 1 consumer wave + 3 producer waves
+constexpr int kChunkStripes = 256;             // 4 KiB per chunk
+constexpr int kRow = kChunkStripes + 4;        // row stride in words: rows land in different banks
+constexpr int kXBuf = 4 * kRow;                // words per buffer
+constexpr int kXLds = 2 * kXBuf;               // words of LDS a caller provides
 
-// v: accumulator `lane` in lanes 0..3.  y: 256 words of LDS.
-__device__ __forceinline__ uint32_t wave_accumulate(const uint8_t *__restrict__ p, size_t stripes,
-                                                    uint32_t v, int lane, uint32_t *y) {
-    const size_t chunks = stripes / kWave;
-    uint64_t a = 0, b = 0;
-    if (chunks) {
-        a = ld64(p + lane * 16);
-        b = ld64(p + lane * 16 + 8);
-    }
-    for (size_t c = 0; c < chunks; c++) {
-        y[lane] = (uint32_t)a * P2;
-        y[64 + lane] = (uint32_t)(a >> 32) * P2;
-        y[128 + lane] = (uint32_t)b * P2;
-        y[192 + lane] = (uint32_t)(b >> 32) * P2;
-        if (c + 1 < chunks) {  // next chunk's loads fly during the chain below
-            const uint8_t *q = p + (c + 1) * (size_t)(kWave * 16) + lane * 16;
-            a = ld64(q);
-            b = ld64(q + 8);
-        }
-        lds_sync();
-        if (lane < 4) {
-            const uint4 *row = reinterpret_cast<const uint4 *>(y + lane * 64);
+__device__ __forceinline__ uint4 ld128(const uint8_t *p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+
+// v: accumulator `lane` in lanes 0..3 of wave 0 (threads 0..3); the result likewise.
+// Every thread of the block must call it (barriers inside).  y: kXLds words of LDS.
+__device__ __forceinline__ uint32_t block_accumulate(const uint8_t *__restrict__ p, size_t stripes,
+                                                     uint32_t v, uint32_t *y) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t chunks = stripes / kChunkStripes;
+    uint4 r[4];
+    auto load = [&](size_t c) {
+        const uint8_t *q = p + c * (size_t)(kChunkStripes * 16) + lane * 16;
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const uint4 t = row[k];
-                v = rol(v + t.x, 13) * P1;
-                v = rol(v + t.y, 13) * P1;
-                v = rol(v + t.z, 13) * P1;
-                v = rol(v + t.w, 13) * P1;
+        for (int j = 0; j < 4; j++) r[j] = ld128(q + j * 1024);
+    };
+    if (wave && (size_t)(wave - 1) < chunks) load(wave - 1);
+    // step s: the producer of chunk s publishes it while the consumer runs chunk s-1
+    for (size_t s = 0; s <= chunks; s++) {
+        if (wave) {
+            if (s < chunks && s % 3 == (size_t)(wave - 1)) {
+                uint32_t *b = y + (s & 1) * kXBuf;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    b[0 * kRow + j * 64 + lane] = r[j].x * P2;
+                    b[1 * kRow + j * 64 + lane] = r[j].y * P2;
+                    b[2 * kRow + j * 64 + lane] = r[j].z * P2;
+                    b[3 * kRow + j * 64 + lane] = r[j].w * P2;
+                }
+                if (s + 3 < chunks) load(s + 3);
+            }
+        } else if (s > 0 && lane < 4) {
+            const uint4 *row = reinterpret_cast<const uint4 *>(y + ((s - 1) & 1) * kXBuf + lane * kRow);
+            for (int g = 0; g < kChunkStripes / 64; g++) {
+                uint4 t[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) t[k] = row[g * 16 + k];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    v = rol(v + t[k].x, 13) * P1;
+                    v = rol(v + t[k].y, 13) * P1;
+                    v = rol(v + t[k].z, 13) * P1;
+                    v = rol(v + t[k].w, 13) * P1;
+                }
             }
         }
-        lds_sync();
+        __syncthreads();
     }
-    if (lane < 4)
-        for (size_t k = chunks * kWave; k < stripes; k++) v = xround(v, ld32(p + k * 16 + lane * 4));
+    if (wave == 0 && lane < 4)
+        for (size_t k = chunks * kChunkStripes; k < stripes; k++) v = xround(v, ld32(p + k * 16 + lane * 4));
     return v;
 }
 
@@ -151,17 +175,17 @@ __device__ __forceinline__ uint32_t merge_accumulators(uint32_t v) {
 // Content checksum: XXHZero over the whole stream.  Sum32 tests uint32(totalLen)
 // >= 16 (xxh32zero.go:113-118), so a stream of 2^32*k + r bytes with r < 16
 // takes the short branch and drops the accumulators; reproduced here.
-__global__ __launch_bounds__(64) void k_xxh32_stream(const uint8_t *__restrict__ src, size_t n,
-                                                     uint32_t *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) uint32_t y[256];
+__global__ __launch_bounds__(kXBlock) void k_xxh32_stream(const uint8_t *__restrict__ src, size_t n,
+                                                          uint32_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint32_t y[kXLds];
     if (blockIdx.x != 0) return;
-    const int lane = lane_id();
+    const int lane = threadIdx.x;
     const uint32_t len_word = (uint32_t)n;
     const size_t stripes = n / 16;
     uint32_t h = len_word;
     if (len_word >= 16) {
         const uint32_t init = lane == 0 ? P1 + P2 : lane == 1 ? P2 : lane == 2 ? 0u : 0u - P1;
-        h += merge_accumulators(wave_accumulate(src, stripes, init, lane, y));
+        h += merge_accumulators(block_accumulate(src, stripes, init, y));
     } else {
         h += P5;  // n < 16, or the truncation quirk: accumulators ignored
     }
@@ -169,18 +193,18 @@ __global__ __launch_bounds__(64) void k_xxh32_stream(const uint8_t *__restrict__
     if (lane == 0) out[0] = xtail(h, src + stripes * 16, n - stripes * 16);
 }
 
-// One WAVE per span (few long spans: a frame of a handful of 4 MiB blocks, the
+// One BLOCK per span (few long spans: a frame of a handful of 4 MiB blocks, the
 // single-block ChecksumZero entry point): the same cooperative accumulate.
-__global__ __launch_bounds__(64) void k_xxh32_spans_wave(const uint8_t *__restrict__ base, size_t n,
+__global__ __launch_bounds__(kXBlock) void k_xxh32_spans_wave(const uint8_t *__restrict__ base, size_t n,
                                                          size_t stride,
                                                          const uint64_t *__restrict__ off,
                                                          const int32_t *__restrict__ len,
                                                          size_t n_spans,
                                                          uint32_t *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) uint32_t y[256];
+    __shared__ __attribute__((aligned(16))) uint32_t y[kXLds];
     const size_t i = blockIdx.x;
     if (i >= n_spans) return;
-    const int lane = lane_id();
+    const int lane = threadIdx.x;
     const size_t o = off ? (size_t)off[i] : i * stride;
     size_t l;
     if (len) {
@@ -194,7 +218,7 @@ __global__ __launch_bounds__(64) void k_xxh32_spans_wave(const uint8_t *__restri
     uint32_t h = (uint32_t)l;
     if (l >= 16) {
         const uint32_t init = lane == 0 ? P1 + P2 : lane == 1 ? P2 : lane == 2 ? 0u : 0u - P1;
-        h += merge_accumulators(wave_accumulate(p, stripes, init, lane, y));
+        h += merge_accumulators(block_accumulate(p, stripes, init, y));
     } else {
         h += P5;
     }
@@ -204,13 +228,13 @@ __global__ __launch_bounds__(64) void k_xxh32_spans_wave(const uint8_t *__restri
 // Chained form of the content checksum for a stream cut across GPUs: state =
 // {v1, v2, v3, v4, totalLen lo, totalLen hi}.  Non-final pieces must be multiples
 // of 16 bytes (block sizes are), so no carry buffer travels (xxh32zero.go:58-86).
-__global__ __launch_bounds__(64) void k_xxh32_update(const uint8_t *__restrict__ src, size_t n,
-                                                     uint32_t *__restrict__ state, int first,
-                                                     int final_piece,
-                                                     uint32_t *__restrict__ digest) {
-    __shared__ __attribute__((aligned(16))) uint32_t y[256];
+__global__ __launch_bounds__(kXBlock) void k_xxh32_update(const uint8_t *__restrict__ src, size_t n,
+                                                          uint32_t *__restrict__ state, int first,
+                                                          int final_piece,
+                                                          uint32_t *__restrict__ digest) {
+    __shared__ __attribute__((aligned(16))) uint32_t y[kXLds];
     if (blockIdx.x != 0) return;
-    const int lane = lane_id();
+    const int lane = threadIdx.x;
     uint32_t v;
     uint64_t total;
     if (first) {  // Reset(): xxh32zero.go:37-44
@@ -221,8 +245,9 @@ __global__ __launch_bounds__(64) void k_xxh32_update(const uint8_t *__restrict__
         total = (uint64_t)state[4] | ((uint64_t)state[5] << 32);
     }
     const size_t stripes = n / 16;
-    v = wave_accumulate(src, stripes, v, lane, y);
+    v = block_accumulate(src, stripes, v, y);
     total += n;
+    __syncthreads();  // every thread has read the incoming state
     if (lane < 4) state[lane] = v;
     if (lane == 0) {
         state[4] = (uint32_t)total;
@@ -239,7 +264,7 @@ __global__ __launch_bounds__(64) void k_xxh32_update(const uint8_t *__restrict__
 
 hipError_t launch_xxh32_update(const uint8_t *src, size_t n, uint32_t *state, int first,
                                int final_piece, uint32_t *digest, hipStream_t st) {
-    hipLaunchKernelGGL(k_xxh32_update, dim3(1), dim3(kWave), 0, st, src, n, state, first,
+    hipLaunchKernelGGL(k_xxh32_update, dim3(1), dim3(kXBlock), 0, st, src, n, state, first,
                        final_piece, digest);
     return hipGetLastError();
 }
@@ -251,7 +276,7 @@ hipError_t launch_xxh32_blocks(const uint8_t *base, size_t n, size_t stride, con
     // Few spans: a lane per span leaves the chip empty and each lane latency-bound;
     // a wave per span streams its span at the accumulator chain's speed instead.
     if (n_spans < 16384) {
-        hipLaunchKernelGGL(k_xxh32_spans_wave, dim3((unsigned)n_spans), dim3(kWave), 0, st, base, n,
+        hipLaunchKernelGGL(k_xxh32_spans_wave, dim3((unsigned)n_spans), dim3(kXBlock), 0, st, base, n,
                            stride, off, len, n_spans, out);
         return hipGetLastError();
     }
@@ -262,7 +287,7 @@ hipError_t launch_xxh32_blocks(const uint8_t *base, size_t n, size_t stride, con
 }
 
 hipError_t launch_xxh32_stream(const uint8_t *src, size_t n, uint32_t *out, hipStream_t st) {
-    hipLaunchKernelGGL(k_xxh32_stream, dim3(1), dim3(kWave), 0, st, src, n, out);
+    hipLaunchKernelGGL(k_xxh32_stream, dim3(1), dim3(kXBlock), 0, st, src, n, out);
     return hipGetLastError();
 }
 
