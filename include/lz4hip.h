@@ -88,7 +88,10 @@ size_t lz4hip_compress_bound(size_t n);
 /* d_workspace (optional): lz4hip_fast_workspace_bytes(n_blocks) bytes, 16-byte
  * aligned.  With a workspace the hash tables live in global memory (L2 /
  * Infinity-Cache resident) and many wavefronts per CU run; with NULL each table
- * lives in LDS, one block per CU.  The output bytes are the same. */
+ * lives in LDS, one block per CU.  The output bytes are the same.  The last 256
+ * bytes of a workspace of the full size hold the block counter of the dynamic
+ * schedule (waves take their next block when they finish one); a workspace that
+ * is a whole number of 128 KiB tables still works, with a round-robin deal. */
 size_t lz4hip_fast_workspace_bytes(size_t n_blocks);
 int lz4hip_compress_fast_blocks(const void *d_src, size_t n, uint32_t block_size, int dst_mode,
                                 void *d_dst, size_t dst_stride, int32_t *d_result,

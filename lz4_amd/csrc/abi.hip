@@ -49,6 +49,7 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 constexpr size_t kFastSlots = 8192;             // resident waves of the global-table Fast kernel
 constexpr size_t kFastSlotBytes = 65536 * 2;    // one u16 table
+constexpr size_t kFastCounterBytes = 256;       // tail of the Fast workspace: the block counter of the dynamic schedule
 constexpr size_t kFastGlobalMinBlocks = 257;    // up to one block per CU the LDS-table kernel is used
 constexpr size_t kHcSlots = 4096;               // resident workgroups of the HC kernel
 constexpr size_t kHcSlotBytes = 65536 * 4 + 65536 * 16 * 2;  // hashTable (u32) + chainTable (16 x u16 links)
@@ -93,12 +94,23 @@ size_t fast_global_min_blocks() {
 }
 hipError_t launch_fast_any(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
                            uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,
-                           uint16_t *ws, size_t slots, hipStream_t st) {
+                           uint16_t *ws, size_t slots, uint32_t *next_block, hipStream_t st) {
     switch (fast_generation()) {
     case 1: return launch_fast(src, n, bs, nb, dst_mode, dst_len_x, dst, dst_stride, result, ws, slots, st);
     case 2: return launch_fast2(src, n, bs, nb, dst_mode, dst_len_x, dst, dst_stride, result, ws, slots, st);
-    default: return launch_fast3(src, n, bs, nb, dst_mode, dst_len_x, dst, dst_stride, result, ws, slots, st);
+    default:
+        return launch_fast3(src, n, bs, nb, dst_mode, dst_len_x, dst, dst_stride, result, ws, slots,
+                            next_block, st);
     }
+}
+// A Fast workspace is `slots` hash tables followed, when the caller sized it with
+// lz4hip_fast_workspace_bytes, by the block counter of the dynamic schedule.  A workspace
+// without room for the counter still works: blocks are then dealt round-robin.
+uint32_t *fast_ws_split(void *ws, size_t bytes, size_t &slots) {
+    slots = ws ? bytes / kFastSlotBytes : 0;
+    if (slots > kFastSlots) slots = kFastSlots;
+    if (!slots || bytes - slots * kFastSlotBytes < sizeof(uint32_t)) return nullptr;
+    return reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(ws) + slots * kFastSlotBytes);
 }
 
 // Decoder generation: 3 = window-parallel two-pass with the window's output staged in
@@ -175,7 +187,7 @@ size_t lz4hip_fast_workspace_bytes(size_t n_blocks) {
     if (n_blocks < fast_global_min_blocks()) return 0;  // LDS-table kernel, no workspace needed
     if (fast_generation() == 4) return n_blocks * kFastSlotBytes;
     const size_t want = 3072;  // 12 waves per CU on 256 CUs: the measured optimum
-    return (n_blocks < want ? n_blocks : want) * kFastSlotBytes;
+    return (n_blocks < want ? n_blocks : want) * kFastSlotBytes + kFastCounterBytes;
 }
 
 int lz4hip_compress_fast_blocks(const void *d_src, size_t n, uint32_t block_size, int dst_mode,
@@ -192,8 +204,8 @@ int lz4hip_compress_fast_blocks(const void *d_src, size_t n, uint32_t block_size
         dst_mode == LZ4HIP_DST_FRAME ? block_size : lz4hip_compress_bound(block_size);
     if (dst_stride < need) return fail(LZ4HIP_ERR_ARG, "dst_stride smaller than dst_len");
     const size_t nb = (n + block_size - 1) / block_size;
-    size_t slots = d_workspace ? workspace_bytes / kFastSlotBytes : 0;
-    if (slots > kFastSlots) slots = kFastSlots;
+    size_t slots = 0;
+    uint32_t *next_block = fast_ws_split(d_workspace, workspace_bytes, slots);
     if (d_workspace && (!aligned16(d_workspace) || slots == 0))
         return fail(LZ4HIP_ERR_ARG, "workspace unaligned or smaller than one table");
     // Few blocks: one block per CU with the table in LDS finishes each block sooner.
@@ -205,7 +217,7 @@ int lz4hip_compress_fast_blocks(const void *d_src, size_t n, uint32_t block_size
         return LZ4HIP_OK;
     }
     HIPCHK(launch_fast_any((const uint8_t *)d_src, n, block_size, nb, dst_mode, 0, (uint8_t *)d_dst,
-                       dst_stride, d_result, (uint16_t *)d_workspace, slots,
+                       dst_stride, d_result, (uint16_t *)d_workspace, slots, next_block,
                        (hipStream_t)stream));
     return LZ4HIP_OK;
 }
@@ -364,7 +376,8 @@ static int64_t compress_one(const uint8_t *src, size_t n, uint8_t *dst, size_t d
                          kHostStream));
     } else {
         HIPCHK(launch_fast_any(d_src.as<uint8_t>(), n, bs, 1, kDstExplicit, (uint32_t)dst_len,
-                           d_dst.as<uint8_t>(), 0, d_res.as<int32_t>(), nullptr, 0, kHostStream));
+                           d_dst.as<uint8_t>(), 0, d_res.as<int32_t>(), nullptr, 0, nullptr,
+                           kHostStream));
     }
     int32_t r = 0;
     HIPCHK(hcopy(&r, d_res.p, sizeof r, hipMemcpyDeviceToHost));
@@ -528,9 +541,11 @@ static int64_t frame_compress(const uint8_t *src, size_t n, uint32_t block_size,
             if (level == 0) {
                 const size_t wsb = lz4hip_fast_workspace_bytes(nb_data);
                 if (wsb) STEP(d_fws.alloc(wsb));
+                size_t slots = 0;
+                uint32_t *next_block = fast_ws_split(d_fws.p, wsb, slots);
                 STEP(launch_fast_any(d_src.as<uint8_t>(), n, block_size, nb_data, dmode, dlen_x,
                                  d_comp.as<uint8_t>(), block_size, d_res.as<int32_t>(),
-                                 d_fws.as<uint16_t>(), wsb / kFastSlotBytes, s_main));
+                                 d_fws.as<uint16_t>(), slots, next_block, s_main));
             } else {
                 DevBuf d_ws;
                 const size_t slots = nb_data < kHcSlots ? nb_data : kHcSlots;

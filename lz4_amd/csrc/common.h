@@ -67,9 +67,11 @@ hipError_t launch_fast(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int
 hipError_t launch_fast2(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
                         uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,
                         uint16_t *ws, size_t slots, hipStream_t st);
+// next_block: one zero-initialisable uint32 in device memory for the dynamic block
+// schedule of the global-table kernel (nullptr: blocks are dealt round-robin).
 hipError_t launch_fast3(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
                         uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,
-                        uint16_t *ws, size_t slots, hipStream_t st);
+                        uint16_t *ws, size_t slots, uint32_t *next_block, hipStream_t st);
 hipError_t launch_fast4(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
                         uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,
                         uint16_t *ws, hipStream_t st);

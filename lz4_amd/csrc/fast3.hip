@@ -422,12 +422,18 @@ __global__ __launch_bounds__(64) void k_fast3_gtab(const uint8_t *__restrict__ s
                                                    uint32_t dst_len_x, uint8_t *__restrict__ dst,
                                                    size_t dst_stride,
                                                    int32_t *__restrict__ result,
-                                                   uint16_t *__restrict__ ws) {
+                                                   uint16_t *__restrict__ ws,
+                                                   uint32_t *__restrict__ next_block) {
     __shared__ uint32_t tag[kTagN];
     __shared__ __attribute__((aligned(16))) uint8_t sbuf[kSrcBuf];
     const int lane = lane_id();
     uint16_t *table = ws + (size_t)blockIdx.x * (1 << 16);
-    for (size_t b = blockIdx.x; b < nb; b += gridDim.x) {
+    // Blocks cost very different amounts of time (incompressible ones a fraction of
+    // text), so a wave takes its next block from a shared counter when it finishes one
+    // (goroutines pulling from the Writer's channel do the same, writer.go:130-142);
+    // without a counter the blocks are dealt round-robin.
+    size_t b = blockIdx.x;
+    while (b < nb) {
         const size_t start = b * (size_t)block_size;
         const size_t left = n_total > start ? n_total - start : 0;
         const int n = (int)(left < block_size ? left : block_size);
@@ -436,17 +442,29 @@ __global__ __launch_bounds__(64) void k_fast3_gtab(const uint8_t *__restrict__ s
                                                    sbuf, lane);
         if (lane == 0) result[b] = r;
         __syncthreads();
+        if (next_block) {
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(next_block, 1u);
+            b = (size_t)gridDim.x + rfl(t);
+        } else {
+            b += gridDim.x;
+        }
     }
 }
 
 hipError_t launch_fast3(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
                         uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,
-                        uint16_t *ws, size_t slots, hipStream_t st) {
+                        uint16_t *ws, size_t slots, uint32_t *next_block, hipStream_t st) {
     if (nb == 0) return hipSuccess;
     if (ws && slots) {
         const size_t grid = nb < slots ? nb : slots;
+        if (grid == nb) next_block = nullptr;  // every block has a wave of its own
+        if (next_block) {
+            const hipError_t e = hipMemsetAsync(next_block, 0, sizeof(uint32_t), st);
+            if (e != hipSuccess) return e;
+        }
         hipLaunchKernelGGL(k_fast3_gtab, dim3((unsigned)grid), dim3(kWave), 0, st, src, n, bs, nb,
-                           dst_mode, dst_len_x, dst, dst_stride, result, ws);
+                           dst_mode, dst_len_x, dst, dst_stride, result, ws, next_block);
     } else {
         hipLaunchKernelGGL(k_fast3_lds, dim3((unsigned)nb), dim3(kWave), 0, st, src, n, bs,
                            dst_mode, dst_len_x, dst, dst_stride, result);

@@ -248,6 +248,30 @@ def test_fast_many_blocks_global_table_kernel(T, oracle):
     _check_blocks(T, oracle, data, bs)
 
 
+@pytest.mark.parametrize("tail", [256, 0])
+def test_fast_block_schedule(T, oracle, tail):
+    """More blocks than workspace tables: with the 256-byte counter tail the waves take
+    blocks dynamically, without it they are dealt round-robin.  Same bytes either way,
+    and again on a second launch that reuses the workspace (the counter is re-armed)."""
+    from lz4_amd import corpus, device as dev
+    bs = 1 << 16
+    data = corpus.generate("mixed", 55, 300 * bs + 17, )
+    data = np.concatenate([data, corpus.generate("text", 9, 90 * bs + 5)])
+    src = _dev(T, data)
+    ws = T.empty(37 * 131072 + tail, dtype=T.uint8, device="cuda")
+    pl, sw, _ = oracle.compress_blocks(data, bs, 0, threads=8)
+    for _ in range(2):
+        comp, res = dev.compress_blocks(src, bs, 0, workspace=ws)
+        res_h, comp_h = res.cpu().numpy(), comp.cpu().numpy()
+        assert res_h.shape[0] == len(sw)
+        for b in range(len(sw)):
+            size = int(sw[b] & 0x7FFFFFFF)
+            if sw[b] >> 31:
+                assert res_h[b] <= 0, b
+            else:
+                assert res_h[b] == size and comp_h[b, :size].tobytes() == pl[b, :size].tobytes(), b
+
+
 @pytest.mark.parametrize("gen", ["1", "2", "4"])
 def test_fast_other_generations(T, oracle, gen, monkeypatch):
     """LZ4HIP_FAST selects the older / experimental Fast kernels (read per call):
