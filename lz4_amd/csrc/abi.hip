@@ -113,18 +113,20 @@ uint32_t *fast_ws_split(void *ws, size_t bytes, size_t &slots) {
     return reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(ws) + slots * kFastSlotBytes);
 }
 
-// Decoder generation: 3 = window-parallel two-pass with the window's output staged in
-// LDS (decode3.hip, default), 2 = the same with direct stores (decode2.hip), 1 = serial
-// walk (decode.hip).  LZ4HIP_DECODE selects an older one for A/B runs (read per call).
+// Decoder generation: 4 = window-parallel two-pass, 192-byte windows with compacted token
+// lanes and the output staged in LDS (decode4.hip, default), 3 = the same with 64-byte
+// windows (decode3.hip), 2 = direct stores (decode2.hip), 1 = serial walk (decode.hip).
+// LZ4HIP_DECODE selects an older one for A/B runs (read per call).
 hipError_t launch_decode_any(const uint8_t *src, const uint64_t *off, const uint32_t *sw, size_t nb,
                              uint8_t *dst, size_t dst_stride, uint32_t dst_len, uint32_t prefix,
                              int32_t *out_len, hipStream_t st) {
     const char *e = getenv("LZ4HIP_DECODE");
-    const int g = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 3;
+    const int g = (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 4;
     switch (g) {
     case 1: return launch_decode(src, off, sw, nb, dst, dst_stride, dst_len, prefix, out_len, st);
     case 2: return launch_decode2(src, off, sw, nb, dst, dst_stride, dst_len, prefix, out_len, st);
-    default: return launch_decode3(src, off, sw, nb, dst, dst_stride, dst_len, prefix, out_len, st);
+    case 3: return launch_decode3(src, off, sw, nb, dst, dst_stride, dst_len, prefix, out_len, st);
+    default: return launch_decode4(src, off, sw, nb, dst, dst_stride, dst_len, prefix, out_len, st);
     }
 }
 

@@ -88,6 +88,9 @@ hipError_t launch_decode2(const uint8_t *src, const uint64_t *off, const uint32_
 hipError_t launch_decode3(const uint8_t *src, const uint64_t *off, const uint32_t *sw, size_t nb,
                           uint8_t *dst, size_t dst_stride, uint32_t dst_len, uint32_t prefix,
                           int32_t *out_len, hipStream_t st);
+hipError_t launch_decode4(const uint8_t *src, const uint64_t *off, const uint32_t *sw, size_t nb,
+                          uint8_t *dst, size_t dst_stride, uint32_t dst_len, uint32_t prefix,
+                          int32_t *out_len, hipStream_t st);
 hipError_t launch_decode2_linked(const uint8_t *src, const uint64_t *off, const uint32_t *sw,
                                  size_t nb, uint8_t *dst, uint32_t block_cap, size_t dst_cap,
                                  int32_t *out_len, uint64_t *out_off, hipStream_t st);

@@ -10,7 +10,7 @@ src = corpus.generate_device(kind, n, dv)
 nb = n // BS
 out = torch.empty((nb, BS), dtype=torch.uint8, device=dv); res = torch.zeros(nb, dtype=torch.int32, device=dv)
 for wpc in [int(a) for a in (sys.argv[4].split(',') if len(sys.argv) > 4 else '4,5,6,8,10,12,16,20,24'.split(','))]:
-    ws = torch.empty(256 * wpc * 131072, dtype=torch.uint8, device=dv)
+    ws = torch.empty(256 * wpc * 131072 + 256, dtype=torch.uint8, device=dv)
     ts = []
     for it in range(3):
         torch.cuda.synchronize(); t = time.perf_counter()
