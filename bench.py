@@ -170,7 +170,7 @@ def main():
         parity["compress_sample_byte_identical"] = bool(ok)
         parity["sampled_blocks"] = len(pick)
 
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N=1 only
             threads = min(len(os.sched_getaffinity(0)), 16)
             m = min(args.cpu_sample_mib << 20, n) // BS_C * BS_C
             h_mixed = mixed[:m].cpu().numpy()

@@ -188,7 +188,7 @@ size_t lz4hip_compress_bound(size_t n) { return n + n / 255 + 16; }
 size_t lz4hip_fast_workspace_bytes(size_t n_blocks) {
     if (n_blocks < fast_global_min_blocks()) return 0;  // LDS-table kernel, no workspace needed
     if (fast_generation() == 4) return n_blocks * kFastSlotBytes;
-    const size_t want = 3072;  // 12 waves per CU on 256 CUs: the measured optimum
+    const size_t want = 3072;  // 12 waves per CU on 256 CUs: the measured plateau
     return (n_blocks < want ? n_blocks : want) * kFastSlotBytes + kFastCounterBytes;
 }
 
@@ -542,7 +542,10 @@ static int64_t frame_compress(const uint8_t *src, size_t n, uint32_t block_size,
         if (nb_data) {
             if (level == 0) {
                 const size_t wsb = lz4hip_fast_workspace_bytes(nb_data);
-                if (wsb) STEP(d_fws.alloc(wsb));
+                if (wsb) {
+                    STEP(d_fws.alloc(wsb));
+                    STEP(hipStreamSynchronize(kHostStream));  // allocated on it, used on s_main
+                }
                 size_t slots = 0;
                 uint32_t *next_block = fast_ws_split(d_fws.p, wsb, slots);
                 STEP(launch_fast_any(d_src.as<uint8_t>(), n, block_size, nb_data, dmode, dlen_x,

@@ -36,6 +36,18 @@ __device__ __forceinline__ uint32_t rfl(uint32_t v) {
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
 
+// Inclusive prefix sum over the 64 lanes with DPP row shifts and row broadcasts (six
+// v_add_u32 with a DPP operand; the shuffle form costs six LDS permutes plus selects).
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // block.go:35-38
 __device__ __forceinline__ uint32_t hash6(uint64_t x) {
     return (uint32_t)(((x << 16) * 227718039650203ULL) >> 48);

@@ -23,10 +23,17 @@ namespace lz4hip {
 
 namespace {
 
-constexpr int kSets = 3;                  // candidate positions per lane
+#ifndef LZ4HIP_DSETS
+#define LZ4HIP_DSETS 3
+#endif
+constexpr int kSets = LZ4HIP_DSETS;       // candidate positions per lane
 constexpr int kWin4 = kSets * kWave;      // compressed bytes per window
 constexpr int kReach4 = kWin4 + 288;      // pass 1 and the literal copies read < si + kReach4
-static_assert(kWin4 / 3 <= kWave, "one lane per token after compaction");
+// A sequence takes at least 3 compressed bytes: 64 positions hold at most 22 tokens, three
+// sets at most 64.  With more sets the link stops before a set that could overflow the
+// 64 token lanes.
+constexpr int kSetTokens = (kWave + 2) / 3;
+static_assert(kSets <= 4 && kWin4 + 275 < 1024, "descriptor fields: 9 + 9 + 10 bits");
 static_assert(kReach4 + 16 <= kIn, "a refill must cover one window");
 
 struct Hdr {  // one candidate sequence header
@@ -135,18 +142,36 @@ __device__ int decode4_block(const uint8_t *__restrict__ in, const int n, uint8_
 #pragma unroll
             for (int j = 0; j < kSets; ++j) {
                 uint64_t Tj = 0;
+                if (kSetTokens * (j + 1) > kWave && go) {  // only sets past the third
+                    int have = 0;
+                    for (int q = 0; q < j; ++q) have += __builtin_popcountll(T[q]);
+                    if (have > kWave - kSetTokens) go = false;
+                }
                 if (go) {
                     const uint64_t Gj = G[j];
                     // compressed length of the sequence that would start at my position
                     const int seqlen = (int)(pk1[j] >> 18) - (kWave * j + lane);
                     int b = t - kWave * j;  // >= 0: a set is entered from the one before
-                    while (b < kWave) {
-                        if (!((Gj >> b) & 1)) {
-                            go = false;
-                            break;
-                        }
-                        Tj |= 1ull << b;
-                        b += (int)rdl((uint32_t)seqlen, b);
+                    if (b < kWave) {
+                        // while (G[b]) { T |= 1 << b; b += seqlen[lane b]; if (b >= 64) break; }
+                        // hand-scheduled: seven scalar instructions per token (the compiler's
+                        // version of the same loop takes twelve)
+                        int tmp;
+                        asm volatile(
+                            "s_nop 1\n\t"  // the lane's seqlen was just written by the VALU
+                            "1:\n\t"
+                            "s_bitcmp1_b64 %[G], %[b]\n\t"
+                            "s_cbranch_scc0 2f\n\t"
+                            "s_bitset1_b64 %[T], %[b]\n\t"
+                            "v_readlane_b32 %[tmp], %[sl], %[b]\n\t"
+                            "s_add_i32 %[b], %[b], %[tmp]\n\t"
+                            "s_cmp_lt_i32 %[b], 64\n\t"
+                            "s_cbranch_scc1 1b\n\t"
+                            "2:"
+                            : [T] "+s"(Tj), [b] "+s"(b), [tmp] "=&s"(tmp)
+                            : [G] "s"(Gj), [sl] "v"(seqlen)
+                            : "scc");
+                        if (b < kWave) go = false;  // stopped at a position that is no plain token
                     }
                     t = b + kWave * j;
                 }
@@ -179,12 +204,7 @@ __device__ int decode4_block(const uint8_t *__restrict__ in, const int n, uint8_
         const int outlen = lit + ml;  // 0 in the lanes past ntok
 
         // exclusive scan of output lengths over the token lanes
-        int incl = outlen;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
-        }
+        const int incl = wave_incl_scan(outlen);
         const int myout = incl - outlen;  // offset of my literals from di
         const int mstart = myout + lit;   // offset of my match from di
         // the reference's bounds: literals and match fit dst, offset inside history

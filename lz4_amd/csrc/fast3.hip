@@ -24,8 +24,16 @@
 
 namespace lz4hip {
 
-constexpr int kSrcBuf = 2048;   // LDS bytes of buffered source per wave
+#ifndef LZ4HIP_SRCBUF
+#define LZ4HIP_SRCBUF 1024
+#endif
+#ifndef LZ4HIP_OUTBUF
+#define LZ4HIP_OUTBUF 512
+#endif
+constexpr int kSrcBuf = LZ4HIP_SRCBUF;   // LDS bytes of buffered source per wave
 constexpr int kSrcReach = 84;   // phase A reads s[wbase-8, wbase+84)
+constexpr int kOutBuf = LZ4HIP_OUTBUF;   // LDS bytes in which a window's sequences are assembled (0: none)
+constexpr int kInUseWords = (1 << 16) / 32;  // block.go:57: inUse [1<<16/32]uint32
 
 // Lane `l` of `old` takes the wave-uniform value `v` (v_cmp + v_cndmask: the VOP3
 // form of v_writelane_b32 cannot take two SGPR operands on gfx9).
@@ -67,6 +75,23 @@ __device__ __forceinline__ int lane_len_tail(uint8_t *p, int v) {
     return k;
 }
 
+// Exact-length global store of the low `len` (< 8) bytes of v.
+__device__ __forceinline__ void store_tail8(uint8_t *p, uint64_t v, int len) {
+    if (len & 4) {
+        const uint32_t w = (uint32_t)v;
+        __builtin_memcpy(p, &w, 4);
+        p += 4;
+        v >>= 32;
+    }
+    if (len & 2) {
+        const uint16_t w = (uint16_t)v;
+        __builtin_memcpy(p, &w, 2);
+        p += 2;
+        v >>= 16;
+    }
+    if (len & 1) *p = (uint8_t)v;
+}
+
 __device__ __forceinline__ int len_tail_size(int len) {  // bytes after the token for `len`
     return len >= 0xF ? 1 + (len - 0xF) / 255 : 0;
 }
@@ -75,13 +100,20 @@ template <bool kGlobal, typename TablePtr>
 __device__ __forceinline__ int fast3_block(const uint8_t *__restrict__ s, const int n,
                                            uint8_t *__restrict__ d, const int dlen,
                                            TablePtr table, uint32_t *tag, uint8_t *sbuf,
-                                           const int lane) {
+                                           uint8_t *obuf, uint32_t *inuse, const int lane) {
     const int bound = (int)compress_bound32((uint32_t)n);
     const bool not_compressible = dlen < bound;  // block.go:110
-    {  // reset(): block.go:94,107 -- an all-zero table is the cleared-bitmap state
-        typedef uint4 __attribute__((may_alias)) uint4_a;
-        uint4_a *t4 = (uint4_a *)(table);
-        for (int k = lane; k < (1 << 16) * 2 / 16; k += kWave) t4[k] = make_uint4(0, 0, 0, 0);
+    {  // reset(): block.go:94,107
+        if (kGlobal) {
+            // the reference's own scheme: clear the in-use bitmap (8 KiB, here in LDS), not the
+            // table.  A get() of an unused slot is answered from the bitmap -- table value 0,
+            // block.go:74-79 -- without touching memory, and the table is never zeroed.
+            for (int k = lane; k < kInUseWords; k += kWave) inuse[k] = 0u;
+        } else {  // LDS table: an all-zero table is the cleared-bitmap state
+            typedef uint4 __attribute__((may_alias)) uint4_a;
+            uint4_a *t4 = (uint4_a *)(table);
+            for (int k = lane; k < (1 << 16) * 2 / 16; k += kWave) t4[k] = make_uint4(0, 0, 0, 0);
+        }
         for (int k = lane; k < kTagN; k += kWave) tag[k] = 0xFFFFFFFFu;
     }
     __syncthreads();
@@ -125,7 +157,12 @@ __device__ __forceinline__ int fast3_block(const uint8_t *__restrict__ s, const 
         if (valid) __builtin_memcpy(&x, sl + p, 8);
         const uint32_t h = hash6(x);
         uint32_t tv = 0;
-        if (valid) tv = tab_load<kGlobal>(table, h);
+        if (kGlobal) {
+            const bool used = valid && ((inuse[h >> 5] >> (h & 31)) & 1u);
+            if (used) tv = tab_load<kGlobal>(table, h);
+        } else if (valid) {
+            tv = tab_load<kGlobal>(table, h);
+        }
         const uint32_t slot = h & (kTagN - 1);
         if (valid) atomicMin(&tag[slot], (uint32_t)lane);
         __asm__ volatile("" ::: "memory");
@@ -323,20 +360,14 @@ __device__ __forceinline__ int fast3_block(const uint8_t *__restrict__ s, const 
             const int m_len = mendv - m_start - kMinMatch;
             const int lt = len_tail_size(l_len), mt = len_tail_size(m_len);
             const int esz = mine ? 1 + lt + l_len + 2 + mt : 0;
-            int incl = esz;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int v = __shfl_up(incl, o);
-                if (lane >= o) incl += v;
-            }
+            const int incl = wave_incl_scan(esz);
             const int total = (int)rdlane((uint32_t)incl, 63);
             if (di + total > dlen) {
                 // some byte of some sequence would land at or beyond len(dst):
                 // ErrInvalidSourceShortBuffer (block.go:196-245)
                 failed = true;
             } else {
-                if (mine) {
-                    uint8_t *o = d + di + (incl - esz);
+                auto emit = [&](uint8_t *o) {
                     *o++ = (uint8_t)((m_len < 0xF ? m_len : 0xF) | ((l_len < 0xF ? l_len : 0xF) << 4));
                     if (l_len >= 0xF) o += lane_len_tail(o, l_len - 0xF);
                     // literals are the bytes just before the match: usually still in sbuf
@@ -349,6 +380,30 @@ __device__ __forceinline__ int fast3_block(const uint8_t *__restrict__ s, const 
                     o[0] = (uint8_t)ofs;
                     o[1] = (uint8_t)(ofs >> 8);
                     if (m_len >= 0xF) lane_len_tail(o + 2, m_len - 0xF);
+                };
+                if (kOutBuf > 0 && total <= kOutBuf) {
+                    // The sequences of a window are a few dozen bytes each and contiguous in
+                    // dst: assemble them in LDS and write them out 16 bytes per lane (two or
+                    // three store requests per window instead of a dozen byte-granular ones).
+                    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the last flush has read obuf
+                    if (mine) emit(obuf + (incl - esz));
+                    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    uint8_t *to = d + di;
+                    for (int k = lane * 16; k < total; k += kWave * 16) {
+                        const uint64_t a = *(const uint64_t *)(obuf + k), b = *(const uint64_t *)(obuf + k + 8);
+                        const int rem = total - k;
+                        if (rem >= 16) {
+                            __builtin_memcpy(to + k, &a, 8);
+                            __builtin_memcpy(to + k + 8, &b, 8);
+                        } else if (rem >= 8) {
+                            __builtin_memcpy(to + k, &a, 8);
+                            store_tail8(to + k + 8, b, rem - 8);
+                        } else {
+                            store_tail8(to + k, a, rem);
+                        }
+                    }
+                } else if (mine) {
+                    emit(d + di + (incl - esz));
                 }
                 di += total;
             }
@@ -364,6 +419,8 @@ __device__ __forceinline__ int fast3_block(const uint8_t *__restrict__ s, const 
                 Pd &= Pd - 1;
                 if (lane == l) table[h] = pos16;
             }
+            __asm__ volatile("" ::: "memory");
+            if (kGlobal && ((P >> lane) & 1)) atomicOr(&inuse[h >> 5], 1u << (h & 31));
             __asm__ volatile("" ::: "memory");
         }
     }
@@ -406,13 +463,15 @@ __global__ __launch_bounds__(64) void k_fast3_lds(const uint8_t *__restrict__ sr
     __shared__ uint16_t table[1 << 16];
     __shared__ uint32_t tag[kTagN];
     __shared__ __attribute__((aligned(16))) uint8_t sbuf[kSrcBuf];
+    __shared__ __attribute__((aligned(16))) uint8_t obuf[kOutBuf + 16];
     const int lane = lane_id();
     const size_t b = blockIdx.x;
     const size_t start = b * (size_t)block_size;
     const size_t left = n_total > start ? n_total - start : 0;
     const int n = (int)(left < block_size ? left : block_size);
     const int r = fast3_block<false>(src + start, n, dst + b * dst_stride,
-                                     block_dlen2(dst_mode, n, dst_len_x), table, tag, sbuf, lane);
+                                     block_dlen2(dst_mode, n, dst_len_x), table, tag, sbuf, obuf,
+                                     nullptr, lane);
     if (lane == 0) result[b] = r;
 }
 
@@ -426,29 +485,35 @@ __global__ __launch_bounds__(64) void k_fast3_gtab(const uint8_t *__restrict__ s
                                                    uint32_t *__restrict__ next_block) {
     __shared__ uint32_t tag[kTagN];
     __shared__ __attribute__((aligned(16))) uint8_t sbuf[kSrcBuf];
+    __shared__ __attribute__((aligned(16))) uint8_t obuf[kOutBuf + 16];
+    __shared__ uint32_t inuse[kInUseWords];
     const int lane = lane_id();
     uint16_t *table = ws + (size_t)blockIdx.x * (1 << 16);
     // Blocks cost very different amounts of time (incompressible ones a fraction of
     // text), so a wave takes its next block from a shared counter when it finishes one
     // (goroutines pulling from the Writer's channel do the same, writer.go:130-142);
     // without a counter the blocks are dealt round-robin.
-    size_t b = blockIdx.x;
+    auto take = [&]() -> size_t {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(next_block, 1u);
+        return (size_t)rfl(t);
+    };
+    // with the counter even the first block is taken from it: a workgroup that only gets a
+    // CU once others have finished must not sit on a block dealt to it in advance
+    size_t b = next_block ? take() : (size_t)blockIdx.x;
     while (b < nb) {
         const size_t start = b * (size_t)block_size;
         const size_t left = n_total > start ? n_total - start : 0;
         const int n = (int)(left < block_size ? left : block_size);
         const int r = fast3_block<true>(src + start, n, dst + b * dst_stride,
                                                    block_dlen2(dst_mode, n, dst_len_x), table, tag,
-                                                   sbuf, lane);
+                                                   sbuf, obuf, inuse, lane);
         if (lane == 0) result[b] = r;
         __syncthreads();
-        if (next_block) {
-            uint32_t t = 0;
-            if (lane == 0) t = atomicAdd(next_block, 1u);
-            b = (size_t)gridDim.x + rfl(t);
-        } else {
+        if (next_block)
+            b = take();
+        else
             b += gridDim.x;
-        }
     }
 }
 

@@ -4,7 +4,10 @@
 
 namespace lz4hip {
 
-constexpr int kTagN = 1024;  // LDS tag slots per wave (u32 each)
+#ifndef LZ4HIP_TAGN
+#define LZ4HIP_TAGN 512
+#endif
+constexpr int kTagN = LZ4HIP_TAGN;  // LDS tag slots per wave (u32 each)
 
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, l);

@@ -15,7 +15,7 @@ run ea TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_6
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 cd $R
-for k in k_fast k_decode2 k_xxh32_blocks; do
+for k in k_fast k_decode k_xxh32_blocks; do
   for p in ea fetch write; do python3 tools/pmc_summary.py $OUT/$p $k; done
 done > $OUT/summary.txt
 cat $OUT/summary.txt

@@ -6,7 +6,7 @@ R=$PWD
 export TMPDIR=/tmp
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
-run() { name=$1; shift; timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 $R/tools/exp_decode.py $GIB text > $OUT/$name.log 2>&1; }
+run() { name=$1; shift; timeout -s KILL 120 rocprofv3 --kernel-include-regex "lz4hip" --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 $R/tools/exp_decode.py $GIB text > $OUT/$name.log 2>&1; }
 cd /tmp
 run tcp TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
 run sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR

@@ -31,7 +31,7 @@ out = {"method": "rocprofv3 --pmc, one run per counter group (TCC_EA0_RDREQ/_32B
                  "FETCH_SIZE + WRITE_SIZE as reported (the x2 FETCH_SIZE correction of MI355X_MICROARCH.md is for wide "
                  "streaming reads; these are random 2-byte gathers)" % gib,
        "input_bytes_per_launch_measured": n}
-for k in ("k_fast3_gtab", "k_decode3", "k_xxh32_blocks"):
+for k in ("k_fast3_gtab", "k_decode4", "k_decode3", "k_xxh32_blocks"):
     if k in vals:
         out[k] = per_byte(vals[k])
 print(json.dumps(out, indent=1))
