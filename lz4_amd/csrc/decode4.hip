@@ -24,7 +24,7 @@ namespace lz4hip {
 namespace {
 
 #ifndef LZ4HIP_DSETS
-#define LZ4HIP_DSETS 3
+#define LZ4HIP_DSETS 4
 #endif
 constexpr int kSets = LZ4HIP_DSETS;       // candidate positions per lane
 constexpr int kWin4 = kSets * kWave;      // compressed bytes per window
