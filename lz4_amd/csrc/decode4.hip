@@ -1,5 +1,5 @@
 // decode4.hip -- window-parallel LZ4 block decoder, generation 4: decode3 with a
-// 192-byte window and compacted token lanes.
+// 256-byte window and compacted token lanes.
 //
 // Same results as decodeBlock (internal/lz4block/decode_other.go:10-137,
 // decode_amd64.s:24-448) / UncompressBlock (block.go:44-52).
@@ -9,12 +9,12 @@
 // every per-window cost (offset scan, bounds ballots, stage hand-offs, flush) is paid
 // per ~105 output bytes.  PMC put it at 1.77 scalar + 0.54 branch + 1.88 vector
 // instructions per output byte: instruction issue, not memory, bounds it.  Here
-//   * pass 1 parses kSets candidate headers per lane (192 compressed bytes; a sequence
-//     takes at least 3, so a window never holds more than 64 real tokens),
+//   * pass 1 parses kSets candidate headers per lane (256 compressed bytes),
 //   * the linked tokens are compacted through LDS into lanes 0..ntok-1 in stream
-//     order, and
-//   * the scan, the bounds and pass 2 run ONCE over the compacted lanes (~27 active on
-//     text), i.e. a third of the per-window instructions per output byte.
+//     order (a sequence takes at least 3 bytes: three sets hold at most 64 tokens, and
+//     the link stops before a fourth set that could overflow the 64 lanes), and
+//   * the scan, the bounds and pass 2 run ONCE over the compacted lanes (~36 active on
+//     text), i.e. a quarter of the per-window instructions per output byte.
 // Unusual sequences (255-run lengths, the block tail, errors) take the same serial
 // path as before; a window whose first byte is not a plain token skips the wide parse.
 #include "decode_common.h"
