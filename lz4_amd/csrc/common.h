@@ -72,6 +72,18 @@ __device__ __forceinline__ void wave_copy(uint8_t *d, const uint8_t *s, int n, i
     for (int k = lane; k < n; k += kWave) d[k] = s[k];
 }
 
+// Wave-wide copy of a long span, 16 bytes per lane (either pointer may be unaligned);
+// the last n % 16 bytes go byte-wise.
+__device__ __forceinline__ void wave_copy16(uint8_t *d, const uint8_t *s, int n, int lane) {
+    const int body = n & ~15;
+    for (int k = lane * 16; k < body; k += kWave * 16) {
+        const uint64_t a = ld64(s + k), b = ld64(s + k + 8);
+        __builtin_memcpy(d + k, &a, 8);
+        __builtin_memcpy(d + k + 8, &b, 8);
+    }
+    wave_copy(d + body, s + body, n - body, lane);
+}
+
 // kernel launchers (defined in the .hip files)
 hipError_t launch_fast(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
                        uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     int r;
     if (w >> 31) {  // stored raw: n := copy(dst, b.data), lz4stream/block.go:320-322
         r = (uint32_t)n > dst_len ? (int)dst_len : n;
-        wave_copy(d, in, r, lane);
+        wave_copy16(d, in, r, lane);
     } else if (n == 0) {
         r = 0;  // block.go:45-47
     } else {

@@ -4,7 +4,7 @@ from lz4_amd import corpus, device as dev
 dv = torch.device('cuda', 0)
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
 only = sys.argv[2] if len(sys.argv) > 2 else None
-for kind, BS in (('text', 1 << 16), ('mixed', 1 << 18)):
+for kind, BS in (('text', 1 << 16), ('mixed', 1 << 18), ('binary', 1 << 18), ('random', 1 << 18)):
     if only and kind != only:
         continue
     n = int(gib * (1 << 30))
