@@ -170,6 +170,70 @@ def test_decode_mutated_blocks_match_oracle_and_stay_in_bounds(T, oracle):
         assert 0 < bad < len(blobs)
 
 
+def _random_block(rng, n_seq, max_lit, max_extra_match, max_off):
+    """A valid LZ4 block built sequence by sequence (not by a compressor): dense tokens,
+    tiny offsets, overlapping matches -- what the Fast parse never emits."""
+    out_len, c = 0, bytearray()
+    first = True
+    for _ in range(n_seq):
+        lit = int(rng.integers(0, max_lit + 1))
+        if first:
+            lit = max(lit, 1)  # the first match needs a byte to copy
+        first = False
+        ml = 4 + int(rng.integers(0, max_extra_match + 1))
+        off = int(rng.integers(1, min(out_len + lit, max_off, 65535) + 1))
+        tok = (min(lit, 15) << 4) | min(ml - 4, 15)
+        c.append(tok)
+        if lit >= 15:
+            v = lit - 15
+            c += b"\xff" * (v // 255) + bytes([v % 255])
+        c += rng.integers(0, 256, lit, dtype=np.uint8).tobytes()
+        c += bytes([off & 0xFF, off >> 8])
+        if ml - 4 >= 15:
+            v = ml - 19
+            c += b"\xff" * (v // 255) + bytes([v % 255])
+        out_len += lit + ml
+    tail = int(rng.integers(5, 12))  # last literals
+    c.append(tail << 4)
+    c += rng.integers(0, 256, tail, dtype=np.uint8).tobytes()
+    return bytes(c), out_len + tail
+
+
+@pytest.mark.parametrize("shape", [(400, 0, 0, 1), (300, 0, 3, 8), (300, 2, 6, 40), (200, 20, 30, 300),
+                                   (150, 3, 300, 70000), (120, 300, 4, 5000)])
+def test_decode_dense_token_streams(T, oracle, shape):
+    """Hand-built blocks of very short sequences (3-byte sequences: 64 tokens in 192
+    compressed bytes), offsets inside the window's own output, 255-run lengths: the token
+    linking across the decoder's header sets, the 64-lane limit, the in-stage match
+    resolution and the serial fall-back against the oracle, with a full and a short dst."""
+    from lz4_amd import device as dev
+    max_lit, max_extra, max_off = shape[1], shape[2], shape[3]
+    rng = np.random.default_rng(1000 + shape[0] + max_lit)
+    blobs, sizes = [], []
+    for i in range(shape[0]):
+        c, n = _random_block(rng, int(rng.integers(1, 700)), max_lit, max_extra, max_off)
+        blobs.append(c)
+        sizes.append(n)
+    dlen = max(sizes)
+    stride = (dlen + 64 + 15) // 16 * 16
+    blob = b"".join(blobs)
+    offs = np.cumsum([0] + [len(b) for b in blobs[:-1]]).astype(np.int64)
+    lens = np.array([len(b) for b in blobs], dtype=np.int32)
+    d_blob = _dev(T, blob)
+    for dst_len in (dlen, max(dlen // 3, 1)):
+        out = T.full((len(blobs), stride), 0xAB, dtype=T.uint8, device="cuda")
+        o, ol = dev.uncompress_blocks(d_blob, T.from_numpy(offs).cuda(), T.from_numpy(lens).cuda(),
+                                      dst_len, out=out, dst_stride=stride)
+        got, outs = ol.cpu().numpy(), o.cpu().numpy()
+        assert (outs[:, dst_len:] == 0xAB).all(), "wrote at or beyond dst_len"
+        for i, c in enumerate(blobs):
+            want, wd = oracle.decodeBlock(c, dst_len)
+            assert (got[i] < 0) == (want < 0), (dst_len, i, got[i], want)
+            if want >= 0:
+                assert want == sizes[i]
+                assert got[i] == want and outs[i, :want].tobytes() == wd[:want].tobytes(), (dst_len, i)
+
+
 @pytest.mark.parametrize("n", [0, 1, 65535, 65536, 65537, 3 * 65536, 1000000])
 @pytest.mark.parametrize("flags", [0, 1, 2, 3, 2 | 8, 3 | 8, 2 | 4])
 def test_frame_compress_device_vs_oracle(T, oracle, n, flags):
