@@ -100,7 +100,9 @@ int lz4hip_compress_fast_blocks(const void *d_src, size_t n, uint32_t block_size
 /* HC level: (*CompressorHC).CompressBlock, internal/lz4block/block.go:319-481,
  * lz4stream/block.go:235-237.  depth = chain depth (0 => 65536); the frame path
  * passes the CompressionLevel constant (options.go:154-165).
- * d_workspace: lz4hip_hc_workspace_bytes(n_blocks) bytes, 256-byte aligned. */
+ * d_workspace: lz4hip_hc_workspace_bytes(n_blocks) bytes, 256-byte aligned (tables
+ * for the resident blocks and, in the last 256 bytes, the counter from which waves
+ * take their next block; without room for it the blocks are dealt round-robin). */
 size_t lz4hip_hc_workspace_bytes(size_t n_blocks);
 int lz4hip_compress_hc_blocks(const void *d_src, size_t n, uint32_t block_size, uint32_t depth,
                               int dst_mode, void *d_dst, size_t dst_stride, int32_t *d_result,

@@ -225,7 +225,8 @@ int lz4hip_compress_fast_blocks(const void *d_src, size_t n, uint32_t block_size
 }
 
 size_t lz4hip_hc_workspace_bytes(size_t n_blocks) {
-    return (n_blocks < kHcSlots ? (n_blocks ? n_blocks : 1) : kHcSlots) * kHcSlotBytes;
+    // the last 256 bytes hold the block counter of the dynamic schedule
+    return (n_blocks < kHcSlots ? (n_blocks ? n_blocks : 1) : kHcSlots) * kHcSlotBytes + kFastCounterBytes;
 }
 
 int lz4hip_compress_hc_blocks(const void *d_src, size_t n, uint32_t block_size, uint32_t depth,
@@ -246,9 +247,14 @@ int lz4hip_compress_hc_blocks(const void *d_src, size_t n, uint32_t block_size, 
     if (slots > kHcSlots) slots = kHcSlots;
     if (slots == 0 || (slots < nb && slots < 64))
         return fail(LZ4HIP_ERR_ARG, "workspace smaller than lz4hip_hc_workspace_bytes(n_blocks)");
+    // room behind the tables for the counter: dynamic schedule; else round-robin
+    uint32_t *next_block =
+        workspace_bytes - slots * kHcSlotBytes >= sizeof(uint32_t)
+            ? reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(d_workspace) + slots * kHcSlotBytes)
+            : nullptr;
     HIPCHK(launch_hc((const uint8_t *)d_src, n, block_size, nb, depth, dst_mode, 0,
                      (uint8_t *)d_dst, dst_stride, d_result, (uint32_t *)d_workspace, slots,
-                     (hipStream_t)stream));
+                     next_block, (hipStream_t)stream));
     return LZ4HIP_OK;
 }
 
@@ -375,7 +381,7 @@ static int64_t compress_one(const uint8_t *src, size_t n, uint8_t *dst, size_t d
         HIPCHK(d_ws.alloc(kHcSlotBytes));
         HIPCHK(launch_hc(d_src.as<uint8_t>(), n, bs, 1, depth, kDstExplicit, (uint32_t)dst_len,
                          d_dst.as<uint8_t>(), 0, d_res.as<int32_t>(), d_ws.as<uint32_t>(), 1,
-                         kHostStream));
+                         nullptr, kHostStream));
     } else {
         HIPCHK(launch_fast_any(d_src.as<uint8_t>(), n, bs, 1, kDstExplicit, (uint32_t)dst_len,
                            d_dst.as<uint8_t>(), 0, d_res.as<int32_t>(), nullptr, 0, nullptr,
@@ -554,10 +560,13 @@ static int64_t frame_compress(const uint8_t *src, size_t n, uint32_t block_size,
             } else {
                 DevBuf d_ws;
                 const size_t slots = nb_data < kHcSlots ? nb_data : kHcSlots;
-                STEP(d_ws.alloc(slots * kHcSlotBytes));
+                STEP(d_ws.alloc(slots * kHcSlotBytes + kFastCounterBytes));
+                STEP(hipStreamSynchronize(kHostStream));  // allocated on it, used on s_main
                 STEP(launch_hc(d_src.as<uint8_t>(), n, block_size, nb_data, level,
                                dmode, dlen_x, d_comp.as<uint8_t>(), block_size,
-                               d_res.as<int32_t>(), d_ws.as<uint32_t>(), slots, s_main));
+                               d_res.as<int32_t>(), d_ws.as<uint32_t>(), slots,
+                               reinterpret_cast<uint32_t *>(d_ws.as<uint8_t>() + slots * kHcSlotBytes),
+                               s_main));
                 STEP(hipStreamSynchronize(s_main));  // d_ws dies with this scope
             }
         }

@@ -102,7 +102,7 @@ hipError_t launch_fast4(const uint8_t *src, size_t n, uint32_t bs, size_t nb, in
 hipError_t launch_hc(const uint8_t *src, size_t n, uint32_t bs, size_t nb, uint32_t depth,
                      int dst_mode,
                      uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result, uint32_t *ws,
-                     size_t slots, hipStream_t st);
+                     size_t slots, uint32_t *next_block, hipStream_t st);
 hipError_t launch_decode(const uint8_t *src, const uint64_t *off, const uint32_t *sw, size_t nb,
                          uint8_t *dst, size_t dst_stride, uint32_t dst_len, uint32_t prefix,
                          int32_t *out_len, hipStream_t st);

@@ -300,7 +300,10 @@ __device__ int decode4_block(const uint8_t *__restrict__ in, const int n, uint8_
 
 }  // namespace
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_decode4(
+#ifndef LZ4HIP_D4_WAVES
+#define LZ4HIP_D4_WAVES 8
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LZ4HIP_D4_WAVES, 8))) void k_decode4(
     const uint8_t *__restrict__ src, const uint64_t *__restrict__ off, const uint32_t *__restrict__ sw,
     size_t nb, uint8_t *dst, size_t dst_stride, uint32_t dst_len, uint32_t prefix,
     int32_t *__restrict__ out_len) {

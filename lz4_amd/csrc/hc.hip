@@ -170,13 +170,23 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                                                     uint32_t depth, int dst_mode, uint32_t dst_len_x,
                                                     uint8_t *__restrict__ dst, size_t dst_stride,
                                                     int32_t *__restrict__ result,
-                                                    uint32_t *__restrict__ ws, size_t nb) {
+                                                    uint32_t *__restrict__ ws, size_t nb,
+                                                    uint32_t *__restrict__ next_block) {
     const int lane = lane_id();
     uint32_t *hash_table = ws + (size_t)blockIdx.x * kHcSlotWords;
     uint16_t *chain_table = reinterpret_cast<uint16_t *>(hash_table + (1 << 16));
     if (depth == 0) depth = kWinSize;  // block.go:343-345
 
-    for (size_t b = blockIdx.x; b < nb; b += gridDim.x) {
+    // resident waves take their next block from a counter when they finish one (as
+    // k_fast3_gtab does; the reference's goroutines, writer.go:130-142); without a counter
+    // the blocks are dealt round-robin
+    auto take = [&]() -> size_t {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(next_block, 1u);
+        return (size_t)rfl(t);
+    };
+    for (size_t b = next_block ? take() : (size_t)blockIdx.x; b < nb;
+         b = next_block ? take() : b + gridDim.x) {
         const uint8_t *s = src + b * (size_t)block_size;
         const size_t start = b * (size_t)block_size;
         const size_t left = n_total > start ? n_total - start : 0;
@@ -363,11 +373,16 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
 hipError_t launch_hc(const uint8_t *src, size_t n, uint32_t bs, size_t nb, uint32_t depth,
                      int dst_mode,
                      uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result, uint32_t *ws,
-                     size_t slots, hipStream_t st) {
+                     size_t slots, uint32_t *next_block, hipStream_t st) {
     if (nb == 0) return hipSuccess;
     const size_t grid = nb < slots ? nb : slots;
+    if (grid == nb || nb > 0xFFFFFFFFull) next_block = nullptr;  // every block has a wave of its own
+    if (next_block) {
+        const hipError_t e = hipMemsetAsync(next_block, 0, sizeof(uint32_t), st);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(k_hc_compress, dim3((unsigned)grid), dim3(kWave), 0, st, src, n, bs, depth,
-                       dst_mode, dst_len_x, dst, dst_stride, result, ws, nb);
+                       dst_mode, dst_len_x, dst, dst_stride, result, ws, nb, next_block);
     return hipGetLastError();
 }
 

@@ -65,9 +65,9 @@ def compress_blocks(src, block_size, level=0, dst_mode=_lib.DST_FRAME, out=None,
                                                    out.data_ptr(), stride, result.data_ptr(),
                                                    ws_ptr, ws_len, _stream_ptr()))
     else:
-        need = lib.lz4hip_hc_workspace_bytes(nb)
-        if workspace is None or workspace.numel() < need:
-            workspace = torch.empty(need, dtype=torch.uint8, device=src.device)
+        if workspace is None:  # a caller's own (possibly smaller) workspace is the ABI's to judge
+            workspace = torch.empty(lib.lz4hip_hc_workspace_bytes(nb), dtype=torch.uint8,
+                                    device=src.device)
         _lib.check(lib.lz4hip_compress_hc_blocks(src.data_ptr(), n, block_size, level, dst_mode,
                                                  out.data_ptr(), stride, result.data_ptr(),
                                                  workspace.data_ptr(), workspace.numel(),

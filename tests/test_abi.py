@@ -70,7 +70,8 @@ def test_argument_validation_without_gpu():
     assert lib.lz4hip_compress_fast_blocks(17, 100, 1 << 16, 0, 16, 65536, 16, None, 0, None) == _lib.ERR_ARG
     assert lib.lz4hip_compress_fast_blocks(16, 100, 1 << 16, 0, 16, 1024, 16, None, 0, None) == _lib.ERR_ARG
     assert lib.lz4hip_uncompress_blocks(None, None, None, 4, None, 0, 0, None, None) == _lib.ERR_ARG
-    assert lib.lz4hip_hc_workspace_bytes(1) == 65536 * 4 + 65536 * 16 * 2   # heads + 16 u16 links per entry
+    # heads + 16 u16 links per entry, + 256 bytes for the block counter of the schedule
+    assert lib.lz4hip_hc_workspace_bytes(1) == 65536 * 4 + 65536 * 16 * 2 + 256
 
 
 def test_no_cpu_fallback_in_product_path():

@@ -336,6 +336,28 @@ def test_fast_block_schedule(T, oracle, tail):
                 assert res_h[b] == size and comp_h[b, :size].tobytes() == pl[b, :size].tobytes(), b
 
 
+@pytest.mark.parametrize("tail", [256, 0])
+def test_hc_block_schedule(T, oracle, tail):
+    """HC with more blocks than workspace slots: counter in the workspace tail (dynamic) or
+    not (round-robin); same bytes, also on a second launch with the same workspace."""
+    from lz4_amd import corpus, device as dev
+    bs = 1 << 16
+    data = corpus.generate("mixed", 77, 150 * bs + 9)
+    src = _dev(T, data)
+    slot = 65536 * 4 + 65536 * 16 * 2
+    ws = T.empty(64 * slot + tail, dtype=T.uint8, device="cuda")
+    pl, sw, _ = oracle.compress_blocks(data, bs, 16, threads=8)
+    for _ in range(2):
+        comp, res = dev.compress_blocks(src, bs, 16, workspace=ws)
+        res_h, comp_h = res.cpu().numpy(), comp.cpu().numpy()
+        for b in range(len(sw)):
+            size = int(sw[b] & 0x7FFFFFFF)
+            if sw[b] >> 31:
+                assert res_h[b] <= 0, b
+            else:
+                assert res_h[b] == size and comp_h[b, :size].tobytes() == pl[b, :size].tobytes(), b
+
+
 @pytest.mark.parametrize("gen", ["1", "2", "4"])
 def test_fast_other_generations(T, oracle, gen, monkeypatch):
     """LZ4HIP_FAST selects the older / experimental Fast kernels (read per call):
