@@ -52,7 +52,6 @@ constexpr size_t kFastSlotBytes = 65536 * 2;    // one u16 table
 constexpr size_t kFastCounterBytes = 256;       // tail of the Fast workspace: the block counter of the dynamic schedule
 constexpr size_t kFastGlobalMinBlocks = 257;    // up to one block per CU the LDS-table kernel is used
 constexpr size_t kHcSlots = 4096;               // resident workgroups of the HC kernel
-constexpr size_t kHcSlotBytes = 65536 * 4 + 65536 * 16 * 2;  // hashTable (u32) + chainTable (16 x u16 links)
 constexpr uint32_t kLegacyBlock = 8u << 20;      // blocks.go:11, frame.go:49
 constexpr size_t kMaxSingleBlock = 1u << 30;    // int32 positions inside a block
 

@@ -23,7 +23,6 @@ namespace lz4hip {
 // positions never change, so links 2.. are link 1 plus the links read from the previous
 // head's entry at insertion time.  A walk then costs one dependent fetch per kHcLinks
 // candidates instead of one per candidate, in the same candidate order.
-constexpr int kHcLinks = 16;
 constexpr int kHcSlotWords = (1 << 16) + (1 << 16) * kHcLinks / 2;
 
 // chainTable[p] = hashTable[hh]; hashTable[hh] = p  (block.go:382-383,401-402), by the
@@ -197,9 +196,10 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                          : dst_mode == LZ4HIP_DST_BOUND ? bound : (int)dst_len_x;
         const bool not_compressible = dlen < bound;  // :330
 
-        {  // zero both tables: :320-324
+        {  // :320-324 zero both tables; here only the heads need it: a chain entry is only
+            // ever reached from a head or a link written in this block, after the entry itself
             uint4 *t4 = reinterpret_cast<uint4 *>(hash_table);
-            for (int k = lane; k < kHcSlotWords / 4; k += kWave) t4[k] = make_uint4(0, 0, 0, 0);
+            for (int k = lane; k < (1 << 16) / 4; k += kWave) t4[k] = make_uint4(0, 0, 0, 0);
         }
         __syncthreads();
 

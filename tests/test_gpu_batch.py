@@ -336,6 +336,11 @@ def test_fast_block_schedule(T, oracle, tail):
                 assert res_h[b] == size and comp_h[b, :size].tobytes() == pl[b, :size].tobytes(), b
 
 
+def _lib_hc_slot():
+    from lz4_amd import _lib
+    return _lib.load().lz4hip_hc_workspace_bytes(1) - 256  # tables of one resident block
+
+
 @pytest.mark.parametrize("tail", [256, 0])
 def test_hc_block_schedule(T, oracle, tail):
     """HC with more blocks than workspace slots: counter in the workspace tail (dynamic) or
@@ -344,7 +349,7 @@ def test_hc_block_schedule(T, oracle, tail):
     bs = 1 << 16
     data = corpus.generate("mixed", 77, 150 * bs + 9)
     src = _dev(T, data)
-    slot = 65536 * 4 + 65536 * 16 * 2
+    slot = _lib_hc_slot()
     ws = T.empty(64 * slot + tail, dtype=T.uint8, device="cuda")
     pl, sw, _ = oracle.compress_blocks(data, bs, 16, threads=8)
     for _ in range(2):
