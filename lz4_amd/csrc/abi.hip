@@ -74,34 +74,8 @@ uint32_t host_xxh32_short(const uint8_t *p, size_t n) {  // n < 16
     return h;
 }
 
-// Kernel generation of the Fast compressor: 3 = window-parallel with vector emission
-// (fast3.hip, default), 2 = window-parallel with scalar emission (fast2.hip),
-// 1 = step-serial (fast.hip), 4 = one lane per block (fast4.hip; needs one table per
-// block in the workspace, only pays with tens of thousands of blocks).  LZ4HIP_FAST
-// selects a non-default one for A/B runs; it is read on every call so that one
-// process can compare generations.
-int fast_generation() {
-    const char *e = getenv("LZ4HIP_FAST");
-    return (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 3;
-}
-// Block count from which the global-table kernel is used (LZ4HIP_FAST_GLOBAL_MIN
-// overrides it for sweeps).
-size_t fast_global_min_blocks() {
-    const char *e = getenv("LZ4HIP_FAST_GLOBAL_MIN");
-    if (e && *e) return (size_t)strtoull(e, nullptr, 10);
-    return kFastGlobalMinBlocks;
-}
-hipError_t launch_fast_any(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
-                           uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,
-                           uint16_t *ws, size_t slots, uint32_t *next_block, hipStream_t st) {
-    switch (fast_generation()) {
-    case 1: return launch_fast(src, n, bs, nb, dst_mode, dst_len_x, dst, dst_stride, result, ws, slots, st);
-    case 2: return launch_fast2(src, n, bs, nb, dst_mode, dst_len_x, dst, dst_stride, result, ws, slots, st);
-    default:
-        return launch_fast3(src, n, bs, nb, dst_mode, dst_len_x, dst, dst_stride, result, ws, slots,
-                            next_block, st);
-    }
-}
+// Block count from which the global-table Fast kernel is used: up to one block per CU the
+// LDS-table kernel finishes each block sooner (k_fast3).
 // A Fast workspace is `slots` hash tables followed, when the caller sized it with
 // lz4hip_fast_workspace_bytes, by the block counter of the dynamic schedule.  A workspace
 // without room for the counter still works: blocks are then dealt round-robin.
@@ -110,23 +84,6 @@ uint32_t *fast_ws_split(void *ws, size_t bytes, size_t &slots) {
     if (slots > kFastSlots) slots = kFastSlots;
     if (!slots || bytes - slots * kFastSlotBytes < sizeof(uint32_t)) return nullptr;
     return reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(ws) + slots * kFastSlotBytes);
-}
-
-// Decoder generation: 4 = window-parallel two-pass, 192-byte windows with compacted token
-// lanes and the output staged in LDS (decode4.hip, default), 3 = the same with 64-byte
-// windows (decode3.hip), 2 = direct stores (decode2.hip), 1 = serial walk (decode.hip).
-// LZ4HIP_DECODE selects an older one for A/B runs (read per call).
-hipError_t launch_decode_any(const uint8_t *src, const uint64_t *off, const uint32_t *sw, size_t nb,
-                             uint8_t *dst, size_t dst_stride, uint32_t dst_len, uint32_t prefix,
-                             int32_t *out_len, hipStream_t st) {
-    const char *e = getenv("LZ4HIP_DECODE");
-    const int g = (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 4;
-    switch (g) {
-    case 1: return launch_decode(src, off, sw, nb, dst, dst_stride, dst_len, prefix, out_len, st);
-    case 2: return launch_decode2(src, off, sw, nb, dst, dst_stride, dst_len, prefix, out_len, st);
-    case 3: return launch_decode3(src, off, sw, nb, dst, dst_stride, dst_len, prefix, out_len, st);
-    default: return launch_decode4(src, off, sw, nb, dst, dst_stride, dst_len, prefix, out_len, st);
-    }
 }
 
 // The host-pointer entry points run on the calling thread's own stream
@@ -185,8 +142,7 @@ int lz4hip_device_count(void) {
 size_t lz4hip_compress_bound(size_t n) { return n + n / 255 + 16; }
 
 size_t lz4hip_fast_workspace_bytes(size_t n_blocks) {
-    if (n_blocks < fast_global_min_blocks()) return 0;  // LDS-table kernel, no workspace needed
-    if (fast_generation() == 4) return n_blocks * kFastSlotBytes;
+    if (n_blocks < kFastGlobalMinBlocks) return 0;  // LDS-table kernel, no workspace needed
     const size_t want = 3072;  // 12 waves per CU on 256 CUs: the measured plateau
     return (n_blocks < want ? n_blocks : want) * kFastSlotBytes + kFastCounterBytes;
 }
@@ -211,13 +167,8 @@ int lz4hip_compress_fast_blocks(const void *d_src, size_t n, uint32_t block_size
         return fail(LZ4HIP_ERR_ARG, "workspace unaligned or smaller than one table");
     // Few blocks: one block per CU with the table in LDS finishes each block sooner.
     // Many blocks: global tables and many waves per CU give the higher throughput.
-    if (nb < fast_global_min_blocks()) slots = 0;
-    if (fast_generation() == 4 && d_workspace && workspace_bytes / kFastSlotBytes >= nb && slots) {
-        HIPCHK(launch_fast4((const uint8_t *)d_src, n, block_size, nb, dst_mode, 0, (uint8_t *)d_dst,
-                            dst_stride, d_result, (uint16_t *)d_workspace, (hipStream_t)stream));
-        return LZ4HIP_OK;
-    }
-    HIPCHK(launch_fast_any((const uint8_t *)d_src, n, block_size, nb, dst_mode, 0, (uint8_t *)d_dst,
+    if (nb < kFastGlobalMinBlocks) slots = 0;
+    HIPCHK(launch_fast((const uint8_t *)d_src, n, block_size, nb, dst_mode, 0, (uint8_t *)d_dst,
                        dst_stride, d_result, (uint16_t *)d_workspace, slots, next_block,
                        (hipStream_t)stream));
     return LZ4HIP_OK;
@@ -267,7 +218,7 @@ int lz4hip_uncompress_blocks(const void *d_src, const uint64_t *d_src_off,
     if (dst_stride < dst_len) return fail(LZ4HIP_ERR_ARG, "dst_stride smaller than dst_len");
     if (dst_len > kMaxSingleBlock) return fail(LZ4HIP_ERR_ARG, "dst_len too large");
     if (n_blocks > 0x7fffffffu) return fail(LZ4HIP_ERR_ARG, "too many blocks");
-    HIPCHK(launch_decode_any((const uint8_t *)d_src, d_src_off, d_size_words, n_blocks,
+    HIPCHK(launch_decode((const uint8_t *)d_src, d_src_off, d_size_words, n_blocks,
                          (uint8_t *)d_dst, dst_stride, dst_len, 0, d_out_len,
                          (hipStream_t)stream));
     return LZ4HIP_OK;
@@ -382,7 +333,7 @@ static int64_t compress_one(const uint8_t *src, size_t n, uint8_t *dst, size_t d
                          d_dst.as<uint8_t>(), 0, d_res.as<int32_t>(), d_ws.as<uint32_t>(), 1,
                          nullptr, kHostStream));
     } else {
-        HIPCHK(launch_fast_any(d_src.as<uint8_t>(), n, bs, 1, kDstExplicit, (uint32_t)dst_len,
+        HIPCHK(launch_fast(d_src.as<uint8_t>(), n, bs, 1, kDstExplicit, (uint32_t)dst_len,
                            d_dst.as<uint8_t>(), 0, d_res.as<int32_t>(), nullptr, 0, nullptr,
                            kHostStream));
     }
@@ -428,7 +379,7 @@ static int64_t uncompress_one(const uint8_t *src, size_t n, uint8_t *dst, size_t
     } meta = {0, (uint32_t)n, 0};
     HIPCHK(hcopy(d_meta.p, &meta, sizeof meta, hipMemcpyHostToDevice));
     uint8_t *m = d_meta.as<uint8_t>();
-    HIPCHK(launch_decode_any(d_src.as<uint8_t>(), (const uint64_t *)m, (const uint32_t *)(m + 8), 1,
+    HIPCHK(launch_decode(d_src.as<uint8_t>(), (const uint64_t *)m, (const uint32_t *)(m + 8), 1,
                          d_out.as<uint8_t>() + dict_len, 0, (uint32_t)dst_len,
                          (uint32_t)dict_len, (int32_t *)(m + 12), kHostStream));
     HIPCHK(hcopy(&meta, d_meta.p, sizeof meta, hipMemcpyDeviceToHost));
@@ -553,7 +504,7 @@ static int64_t frame_compress(const uint8_t *src, size_t n, uint32_t block_size,
                 }
                 size_t slots = 0;
                 uint32_t *next_block = fast_ws_split(d_fws.p, wsb, slots);
-                STEP(launch_fast_any(d_src.as<uint8_t>(), n, block_size, nb_data, dmode, dlen_x,
+                STEP(launch_fast(d_src.as<uint8_t>(), n, block_size, nb_data, dmode, dlen_x,
                                  d_comp.as<uint8_t>(), block_size, d_res.as<int32_t>(),
                                  d_fws.as<uint16_t>(), slots, next_block, s_main));
             } else {
@@ -768,7 +719,7 @@ static int64_t legacy_uncompress(const uint8_t *src, size_t n, size_t si, uint8_
         HIPCHK(hcopy(d_src.p, src, n, hipMemcpyHostToDevice));
         HIPCHK(hcopy(d_off.p, off.data(), nb * 8, hipMemcpyHostToDevice));
         HIPCHK(hcopy(d_sw.p, sw.data(), nb * 4, hipMemcpyHostToDevice));
-        HIPCHK(launch_decode_any(d_src.as<uint8_t>(), d_off.as<uint64_t>(), d_sw.as<uint32_t>(), nb,
+        HIPCHK(launch_decode(d_src.as<uint8_t>(), d_off.as<uint64_t>(), d_sw.as<uint32_t>(), nb,
                                  d_out.as<uint8_t>(), cap, cap, 0, d_len.as<int32_t>(), kHostStream));
         HIPCHK(hcopy(len.data(), d_len.p, nb * 4, hipMemcpyDeviceToHost));
     }
@@ -885,14 +836,14 @@ static int64_t frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size
     for (size_t b0 = 0; b0 < nb; b0 += chunk) {
         const size_t c = std::min(chunk, nb - b0);
         if (independent) {
-            HIPCHK(launch_decode_any(d_src.as<uint8_t>(), d_off.as<uint64_t>() + b0,
+            HIPCHK(launch_decode(d_src.as<uint8_t>(), d_off.as<uint64_t>() + b0,
                                      d_sw.as<uint32_t>() + b0, c, d_slots.as<uint8_t>(), bs, bs, 0,
                                      d_len.as<int32_t>(), kHostStream));
             if (bsum)  // verified on the DECODED bytes: lz4stream/block.go:330-335
                 HIPCHK(launch_xxh32_blocks(d_slots.as<uint8_t>(), c * (size_t)bs, bs, nullptr,
                                            d_len.as<int32_t>(), c, d_xxh.as<uint32_t>(), kHostStream));
         } else {  // reader.go:86-90,176-189: dependent blocks decode in order, output packed
-            HIPCHK(launch_decode2_linked(d_src.as<uint8_t>(), d_off.as<uint64_t>(), d_sw.as<uint32_t>(),
+            HIPCHK(launch_decode_linked(d_src.as<uint8_t>(), d_off.as<uint64_t>(), d_sw.as<uint32_t>(),
                                          nb, d_flat.as<uint8_t>(), bs, flat_cap, d_len.as<int32_t>(),
                                          d_foff.as<uint64_t>(), kHostStream));
             if (bsum)

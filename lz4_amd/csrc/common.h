@@ -92,20 +92,11 @@ __device__ __forceinline__ void wave_copy16(uint8_t *d, const uint8_t *s, int n,
 }
 
 // kernel launchers (defined in the .hip files)
-hipError_t launch_fast(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
-                       uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,
-                       uint16_t *ws, size_t slots, hipStream_t st);
-hipError_t launch_fast2(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
-                        uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,
-                        uint16_t *ws, size_t slots, hipStream_t st);
 // next_block: one zero-initialisable uint32 in device memory for the dynamic block
 // schedule of the global-table kernel (nullptr: blocks are dealt round-robin).
-hipError_t launch_fast3(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
-                        uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,
-                        uint16_t *ws, size_t slots, uint32_t *next_block, hipStream_t st);
-hipError_t launch_fast4(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
-                        uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,
-                        uint16_t *ws, hipStream_t st);
+hipError_t launch_fast(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
+                       uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,
+                       uint16_t *ws, size_t slots, uint32_t *next_block, hipStream_t st);
 hipError_t launch_hc(const uint8_t *src, size_t n, uint32_t bs, size_t nb, uint32_t depth,
                      int dst_mode,
                      uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result, uint32_t *ws,
@@ -113,18 +104,9 @@ hipError_t launch_hc(const uint8_t *src, size_t n, uint32_t bs, size_t nb, uint3
 hipError_t launch_decode(const uint8_t *src, const uint64_t *off, const uint32_t *sw, size_t nb,
                          uint8_t *dst, size_t dst_stride, uint32_t dst_len, uint32_t prefix,
                          int32_t *out_len, hipStream_t st);
-hipError_t launch_decode2(const uint8_t *src, const uint64_t *off, const uint32_t *sw, size_t nb,
-                          uint8_t *dst, size_t dst_stride, uint32_t dst_len, uint32_t prefix,
-                          int32_t *out_len, hipStream_t st);
-hipError_t launch_decode3(const uint8_t *src, const uint64_t *off, const uint32_t *sw, size_t nb,
-                          uint8_t *dst, size_t dst_stride, uint32_t dst_len, uint32_t prefix,
-                          int32_t *out_len, hipStream_t st);
-hipError_t launch_decode4(const uint8_t *src, const uint64_t *off, const uint32_t *sw, size_t nb,
-                          uint8_t *dst, size_t dst_stride, uint32_t dst_len, uint32_t prefix,
-                          int32_t *out_len, hipStream_t st);
-hipError_t launch_decode2_linked(const uint8_t *src, const uint64_t *off, const uint32_t *sw,
-                                 size_t nb, uint8_t *dst, uint32_t block_cap, size_t dst_cap,
-                                 int32_t *out_len, uint64_t *out_off, hipStream_t st);
+hipError_t launch_decode_linked(const uint8_t *src, const uint64_t *off, const uint32_t *sw,
+                                size_t nb, uint8_t *dst, uint32_t block_cap, size_t dst_cap,
+                                int32_t *out_len, uint64_t *out_off, hipStream_t st);
 hipError_t launch_xxh32_blocks(const uint8_t *base, size_t n, size_t stride, const uint64_t *off,
                                const int32_t *len, size_t n_spans, uint32_t *out, hipStream_t st);
 hipError_t launch_xxh32_stream(const uint8_t *src, size_t n, uint32_t *out, hipStream_t st);

@@ -1,81 +1,315 @@
-// decode.hip -- LZ4 block decoder for gfx950.
+// decode4.hip -- window-parallel LZ4 block decoder, generation 4: decode3 with a
+// 256-byte window and compacted token lanes.
 //
-// Restates decodeBlock, internal/lz4block/decode_other.go:10-137 (semantics) /
-// decode_amd64.s:24-448, and UncompressBlock, block.go:44-52.  One wavefront
-// per independent block.  The sequence walk is wave-uniform; length runs,
-// literal copies and match copies are 64 lanes wide.  A match is written as
-// the periodic extension of the `offset` bytes before it, which equals the
-// reference's byte-serial overlap copy (decode_amd64.s:290-300) and has no
-// dependency inside the match.  Every bound is checked before a byte is
-// stored, so nothing is ever written at or beyond dst_len.
-#include "common.h"
+// Same results as decodeBlock (internal/lz4block/decode_other.go:10-137,
+// decode_amd64.s:24-448) / UncompressBlock (block.go:44-52).
+//
+// decode3 parses 64 compressed bytes per window; on text that is ~9 sequences, so
+// pass 2 (the copies, with their divergent tails) runs with 9 of 64 lanes active and
+// every per-window cost (offset scan, bounds ballots, stage hand-offs, flush) is paid
+// per ~105 output bytes.  PMC put it at 1.77 scalar + 0.54 branch + 1.88 vector
+// instructions per output byte: instruction issue, not memory, bounds it.  Here
+//   * pass 1 parses kSets candidate headers per lane (256 compressed bytes),
+//   * the linked tokens are compacted through LDS into lanes 0..ntok-1 in stream
+//     order (a sequence takes at least 3 bytes: three sets hold at most 64 tokens, and
+//     the link stops before a fourth set that could overflow the 64 lanes), and
+//   * the scan, the bounds and pass 2 run ONCE over the compacted lanes (~36 active on
+//     text), i.e. a quarter of the per-window instructions per output byte.
+// Unusual sequences (255-run lengths, the block tail, errors) take the same serial
+// path as before; a window whose first byte is not a plain token skips the wide parse.
+#include "decode_common.h"
 
 namespace lz4hip {
 
-// Adds the 255-run length extension that starts at in[p]; returns false when the
-// input ends inside it (decode_other.go:62-71,96-105 index panics).
-__device__ __forceinline__ bool read_len_ext(const uint8_t *in, int n, int &p, int &len, int lane) {
+namespace {
+
+#ifndef LZ4HIP_DSETS
+#define LZ4HIP_DSETS 4
+#endif
+constexpr int kSets = LZ4HIP_DSETS;       // candidate positions per lane
+constexpr int kWin4 = kSets * kWave;      // compressed bytes per window
+constexpr int kReach4 = kWin4 + 288;      // pass 1 and the literal copies read < si + kReach4
+// A sequence takes at least 3 compressed bytes: 64 positions hold at most 22 tokens, three
+// sets at most 64.  With more sets the link stops before a set that could overflow the
+// 64 token lanes.
+constexpr int kSetTokens = (kWave + 2) / 3;
+static_assert(kSets <= 4 && kWin4 + 275 < 1024, "descriptor fields: 9 + 9 + 10 bits");
+static_assert(kReach4 + 16 <= kIn, "a refill must cover one window");
+
+struct Hdr {  // one candidate sequence header
+    bool ok;
+    int lit, ml, off, lpos, end;  // lpos, end: absolute compressed positions
+};
+
+// Parses the header that would start at in[pos] (decode_other.go:24-32,59-107 for the
+// plain case: lengths below 15+255, 16 literal bytes readable, another token follows).
+__device__ __forceinline__ Hdr parse_header(const uint8_t *ib, const int pos, const int n) {
+    Hdr h;
+    bool ok = pos + 18 <= n;
+    uint32_t w0 = 0u;
+    if (ok) __builtin_memcpy(&w0, ib + pos, 4);
+    const uint32_t tok = w0 & 0xFFu;
+    int lit = (int)(tok >> 4), e1 = 0;
+    if (lit == 0xF) {
+        const uint32_t b1 = (w0 >> 8) & 0xFFu;
+        lit += (int)b1;
+        e1 = 1;
+        ok = ok && b1 != 255u;
+    }
+    const int lpos = pos + 1 + e1;  // first literal
+    const int opos = lpos + lit;    // offset field
+    ok = ok && opos + 4 <= n && (lit <= 16 || lpos + ((lit + 15) & ~15) <= n);
+    uint32_t w1 = 0u;
+    if (ok) __builtin_memcpy(&w1, ib + opos, 4);
+    h.off = (int)(w1 & 0xFFFFu);
+    int ml = (int)(tok & 0xFu) + kMinMatch, e2 = 0;
+    if ((tok & 0xFu) == 0xFu) {
+        const uint32_t b2 = (w1 >> 16) & 0xFFu;
+        ml += (int)b2;
+        e2 = 1;
+        ok = ok && b2 != 255u;
+    }
+    h.end = opos + 2 + e2;
+    // another token must follow: the last sequences go through the serial path
+    h.ok = ok && h.off != 0 && h.end < n;
+    h.lit = lit;
+    h.ml = ml;
+    h.lpos = lpos;
+    return h;
+}
+
+// `stage`: kStage bytes of LDS owned by this wave, 16-byte aligned; `ibuf`: kIn bytes
+// of LDS holding in[ibase, iend) (one coalesced refill per ~8 windows); `desc`: 64
+// token descriptors.
+__device__ int decode4_block(const uint8_t *__restrict__ in, const int n, uint8_t *d, const int dlen,
+                             const int prefix, const int lane, uint8_t *stage, uint8_t *ibuf,
+                             uint2 *desc) {
+    int si = 0, di = 0, ibase = 0, iend = 0;
     for (;;) {
-        const int idx = p + lane;
-        const bool valid = idx < n;
-        const uint32_t x = valid ? in[idx] : 0u;
-        const uint64_t stop = ballot(!valid || x != 255u);
-        if (stop == 0) {
-            len += 255 * kWave;
-            p += kWave;
-            if (len < 0) return false;
+        si = (int)rfl((uint32_t)si);
+        di = (int)rfl((uint32_t)di);
+        if (si >= n) return di;
+        ibase = (int)rfl((uint32_t)ibase);
+        iend = (int)rfl((uint32_t)iend);
+        if (si + kReach4 > iend && iend < n) {
+            ibase = si;
+            const int cnt = n - ibase < kIn ? n - ibase : kIn;
+            lds_sync();
+            for (int k = lane * 16; k < cnt; k += kWave * 16) {
+                if (k + 16 <= cnt) {
+                    const uint64_t a = ld64(in + ibase + k), b = ld64(in + ibase + k + 8);
+                    *(uint64_t *)(ibuf + k) = a;
+                    *(uint64_t *)(ibuf + k + 8) = b;
+                } else {
+                    for (int j = k; j < cnt; j++) ibuf[j] = in[ibase + j];
+                }
+            }
+            iend = ibase + cnt;
+            lds_sync();
+        }
+        const uint8_t *ib = ibuf - ibase;  // ib[p] = in[p] for ibase <= p < iend
+
+        // ---------------- pass 1: parse kSets x 64 candidate headers ----------------
+        // set j, lane l <-> position si + 64 j + l
+        uint32_t pk0[kSets], pk1[kSets];
+        uint64_t G[kSets];
+        {
+            const Hdr h = parse_header(ib, si + lane, n);
+            G[0] = ballot(h.ok);
+            pk0[0] = (uint32_t)h.off | ((uint32_t)h.lit << 16);
+            pk1[0] = (uint32_t)h.ml | ((uint32_t)(h.lpos - si) << 9) | ((uint32_t)(h.end - si) << 18);
+        }
+        if (!(G[0] & 1)) {  // the sequence at si itself is not a plain one
+            const int st = d2_serial_sequence(in, n, d, dlen, prefix, si, di, lane);
+            if (st < 0) return -1;
+            if (st > 0) return di;
             continue;
         }
-        const int k = __builtin_ctzll(stop);
-        if (p + k >= n) return false;
-        len += 255 * k + (int)__shfl((int)x, k);
-        p += k + 1;
-        return len >= 0;
-    }
-}
-
-// Returns bytes written or -1.
-// `prefix` bytes of history precede d in memory (external dictionary laid out in
-// front of dst: decode_other.go:109-121); 0 in the batched path.
-__device__ int decode_block_wave(const uint8_t *__restrict__ in, int n, uint8_t *d, int dlen,
-                                 int prefix, int lane) {
-    int si = 0, di = 0;
-    while (si < n) {
-        const uint32_t tok = in[si++];
-        int l_len = (int)(tok >> 4);
-        if (l_len > 0) {
-            if (l_len == 0xF && !read_len_ext(in, n, si, l_len, lane)) return -1;
-            if (l_len > n - si || l_len > dlen - di) return -1;
-            wave_copy(d + di, in + si, l_len, lane);
-            si += l_len;
-            di += l_len;
+#pragma unroll
+        for (int j = 1; j < kSets; ++j) {
+            const int pos = si + kWave * j + lane;
+            const Hdr h = parse_header(ib, pos, n);
+            G[j] = ballot(h.ok);
+            pk0[j] = (uint32_t)h.off | ((uint32_t)h.lit << 16);
+            pk1[j] = (uint32_t)h.ml | ((uint32_t)(h.lpos - si) << 9) | ((uint32_t)(h.end - si) << 18);
         }
-        int m_len = (int)(tok & 0xF);
-        if (si == n && m_len == 0) break;  // decode_other.go:81-82
-        if (n - si < 2) return -1;         // :83-87
-        const int offset = (int)in[si] | ((int)in[si + 1] << 8);
-        if (offset == 0) return -1;  // :88-90
-        si += 2;
-        m_len += kMinMatch;
-        if (m_len == kMinMatch + 0xF && !read_len_ext(in, n, si, m_len, lane)) return -1;
-        if (m_len > dlen - di) return -1;
-        if (offset > di + prefix) return -1;  // before the dictionary start: :109-113
-        const uint8_t *from = d + di - offset;
-        if (m_len <= offset) {
-            wave_copy(d + di, from, m_len, lane);
+
+        // ---------------- link the real tokens (wave-uniform) ----------------
+        uint64_t T[kSets];
+        {
+            int t = 0;  // window-relative position of the next token
+            bool go = true;
+#pragma unroll
+            for (int j = 0; j < kSets; ++j) {
+                uint64_t Tj = 0;
+                if (kSetTokens * (j + 1) > kWave && go) {  // only sets past the third
+                    int have = 0;
+                    for (int q = 0; q < j; ++q) have += __builtin_popcountll(T[q]);
+                    if (have > kWave - kSetTokens) go = false;
+                }
+                if (go) {
+                    const uint64_t Gj = G[j];
+                    // compressed length of the sequence that would start at my position
+                    const int seqlen = (int)(pk1[j] >> 18) - (kWave * j + lane);
+                    int b = t - kWave * j;  // >= 0: a set is entered from the one before
+                    if (b < kWave) {
+                        // while (G[b]) { T |= 1 << b; b += seqlen[lane b]; if (b >= 64) break; }
+                        // hand-scheduled: seven scalar instructions per token (the compiler's
+                        // version of the same loop takes twelve)
+                        int tmp;
+                        asm volatile(
+                            "s_nop 1\n\t"  // the lane's seqlen was just written by the VALU
+                            "1:\n\t"
+                            "s_bitcmp1_b64 %[G], %[b]\n\t"
+                            "s_cbranch_scc0 2f\n\t"
+                            "s_bitset1_b64 %[T], %[b]\n\t"
+                            "v_readlane_b32 %[tmp], %[sl], %[b]\n\t"
+                            "s_add_i32 %[b], %[b], %[tmp]\n\t"
+                            "s_cmp_lt_i32 %[b], 64\n\t"
+                            "s_cbranch_scc1 1b\n\t"
+                            "2:"
+                            : [T] "+s"(Tj), [b] "+s"(b), [tmp] "=&s"(tmp)
+                            : [G] "s"(Gj), [sl] "v"(seqlen)
+                            : "scc");
+                        if (b < kWave) go = false;  // stopped at a position that is no plain token
+                    }
+                    t = b + kWave * j;
+                }
+                T[j] = Tj;
+            }
+        }
+
+        // ---------------- compact: token r of the window -> lane r ----------------
+        int ntok = 0;
+        lds_sync();  // the previous window's descriptor reads are done
+#pragma unroll
+        for (int j = 0; j < kSets; ++j) {
+            const uint64_t Tj = T[j];
+            if ((Tj >> lane) & 1) {
+                const int r = ntok + (int)__builtin_amdgcn_mbcnt_hi(
+                                         (uint32_t)(Tj >> 32),
+                                         __builtin_amdgcn_mbcnt_lo((uint32_t)Tj, 0u));
+                desc[r] = make_uint2(pk0[j], pk1[j]);
+            }
+            ntok += __builtin_popcountll(Tj);
+        }
+        lds_sync();
+        uint2 dsc = make_uint2(0u, 0u);
+        if (lane < ntok) dsc = desc[lane];
+        const int off = (int)(dsc.x & 0xFFFFu);
+        const int lit = (int)(dsc.x >> 16);
+        const int ml = (int)(dsc.y & 0x1FFu);
+        const int lpos = si + (int)((dsc.y >> 9) & 0x1FFu);
+        const int endrel = (int)(dsc.y >> 18);
+        const int outlen = lit + ml;  // 0 in the lanes past ntok
+
+        // exclusive scan of output lengths over the token lanes
+        const int incl = wave_incl_scan(outlen);
+        const int myout = incl - outlen;  // offset of my literals from di
+        const int mstart = myout + lit;   // offset of my match from di
+        // the reference's bounds: literals and match fit dst, offset inside history
+        const bool bad = lane < ntok && (di + mstart + ml > dlen || off > di + mstart + prefix);
+        const uint64_t B = ballot(bad);
+        if (B) ntok = __builtin_ctzll(B);  // stop before the first violation
+        if (ntok == 0) {
+            const int st = d2_serial_sequence(in, n, d, dlen, prefix, si, di, lane);
+            if (st < 0) return -1;
+            if (st > 0) return di;
+            continue;
+        }
+        const bool act = lane < ntok;
+        const int adv_c = (int)rdl((uint32_t)endrel, ntok - 1);            // compressed bytes consumed
+        const int adv_o = (int)rdl((uint32_t)(myout + outlen), ntok - 1);  // output bytes produced
+
+        // ---------------- pass 2: copies ----------------
+        if (adv_o <= kStage) {
+            lds_sync();  // the previous window's flush has read the stage
+            // literals (16 bytes readable after every token: ok => pos + 18 <= n)
+            if (act && lit > 0) s2s_over(stage + myout, ib + lpos, lit);
+            // leading g bytes of every match come from output older than this window
+            int g = 0;
+            if (act) {
+                g = off - mstart;
+                g = g < 0 ? 0 : (g > ml ? ml : g);
+                if (g > 0) g2s_exact(stage + mstart, d + di + mstart - off, g);
+            }
+            lds_sync();
+            // the rest reads this window's own output: stream order, inside the stage
+            uint64_t D = ballot(act && g < ml);
+            while (D) {
+                const int l = __builtin_ctzll(D);
+                D &= D - 1;
+                const int o_ms = (int)rdl((uint32_t)mstart, l);
+                const int o_ml = (int)rdl((uint32_t)ml, l);
+                const int o_off = (int)rdl((uint32_t)off, l);
+                const int o_g = (int)rdl((uint32_t)g, l);
+                // first period (or the whole match): sources end before the match starts
+                const int p1 = o_ml < o_off ? o_ml : o_off;
+                for (int k = o_g + lane; k < p1; k += kWave) stage[o_ms + k] = stage[o_ms + k - o_off];
+                lds_sync();
+                // overlap: periodic extension of the first `offset` bytes of the match
+                if (o_ml > o_off) {
+                    for (int k = o_off + lane; k < o_ml; k += kWave)
+                        stage[o_ms + k] = stage[o_ms + k % o_off];
+                    lds_sync();
+                }
+            }
+            // flush: 16 bytes per lane, contiguous across the wave
+            uint8_t *to = d + di;
+            for (int k = lane * 16; k < adv_o; k += kWave * 16) {
+                const uint64_t a = *(const uint64_t *)(stage + k), b = *(const uint64_t *)(stage + k + 8);
+                const int rem = adv_o - k;
+                if (rem >= 16) {
+                    __builtin_memcpy(to + k, &a, 8);
+                    __builtin_memcpy(to + k + 8, &b, 8);
+                } else if (rem >= 8) {
+                    __builtin_memcpy(to + k, &a, 8);
+                    store_tail(to + k + 8, b, rem - 8);
+                } else {
+                    store_tail(to + k, a, rem);
+                }
+            }
         } else {
-            for (int k = lane; k < m_len; k += kWave) d[di + k] = from[k % offset];
+            // window output larger than the stage: direct copies
+            if (act && lit > 0) lane_copy16(d + di + myout, in + lpos, lit);
+            // matches whose source ends before this window's output, and whose 16-byte
+            // chunk reads stay inside dst
+            const bool indep = act && off >= mstart + ml && di + mstart + ((ml + 15) & ~15) <= dlen;
+            if (indep) lane_copy16(d + di + mstart, d + di + mstart - off, ml);
+            // the rest in stream order, 64 lanes wide
+            uint64_t D = ballot(act && !indep);
+            while (D) {
+                const int l = __builtin_ctzll(D);
+                D &= D - 1;
+                const int o_ms = (int)rdl((uint32_t)mstart, l);
+                const int o_ml = (int)rdl((uint32_t)ml, l);
+                const int o_off = (int)rdl((uint32_t)off, l);
+                uint8_t *to = d + di + o_ms;
+                const uint8_t *from = to - o_off;
+                if (o_ml <= o_off) {
+                    wave_copy(to, from, o_ml, lane);
+                } else {
+                    for (int k = lane; k < o_ml; k += kWave) to[k] = from[k % o_off];
+                }
+            }
         }
-        di += m_len;
+        si += adv_c;
+        di += adv_o;
     }
-    return di;
 }
 
-__global__ __launch_bounds__(64) void k_decode(const uint8_t *__restrict__ src,
-                                               const uint64_t *__restrict__ off,
-                                               const uint32_t *__restrict__ sw, size_t nb,
-                                               uint8_t *dst, size_t dst_stride, uint32_t dst_len,
-                                               uint32_t prefix, int32_t *__restrict__ out_len) {
+}  // namespace
+
+#ifndef LZ4HIP_D4_WAVES
+#define LZ4HIP_D4_WAVES 8
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LZ4HIP_D4_WAVES, 8))) void k_decode4(
+    const uint8_t *__restrict__ src, const uint64_t *__restrict__ off, const uint32_t *__restrict__ sw,
+    size_t nb, uint8_t *dst, size_t dst_stride, uint32_t dst_len, uint32_t prefix,
+    int32_t *__restrict__ out_len) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kStage + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t ibuf[kIn + 16];
+    __shared__ uint2 desc[kWave];
     const int lane = lane_id();
     const size_t b = blockIdx.x;
     if (b >= nb) return;
@@ -86,20 +320,83 @@ __global__ __launch_bounds__(64) void k_decode(const uint8_t *__restrict__ src,
     int r;
     if (w >> 31) {  // stored raw: n := copy(dst, b.data), lz4stream/block.go:320-322
         r = (uint32_t)n > dst_len ? (int)dst_len : n;
-        wave_copy(d, in, r, lane);
+        wave_copy16(d, in, r, lane);
     } else if (n == 0) {
         r = 0;  // block.go:45-47
     } else {
-        r = decode_block_wave(in, n, d, (int)dst_len, (int)prefix, lane);
+        r = decode4_block(in, n, d, (int)dst_len, (int)prefix, lane, stage, ibuf, desc);
     }
     if (lane == 0) out_len[b] = r;
 }
 
-hipError_t launch_decode(const uint8_t *src, const uint64_t *off, const uint32_t *sw, size_t nb,
-                         uint8_t *dst, size_t dst_stride, uint32_t dst_len, uint32_t prefix,
-                         int32_t *out_len, hipStream_t st) {
+// Linked-block frame (FLG bit 5 clear): every block may reference the 64 KiB of
+// output before it (reader.go:176-189 keeps that history as the dictionary), so the
+// blocks of one frame decode in stream order by ONE wave into one contiguous buffer,
+// where "the dictionary" is simply the output already written: prefix = bytes so far.
+// The reader's history holds at least min(bytes so far, 64 KiB) and offsets are
+// < 64 KiB, so `offset > di + len(dict)` fires exactly when `offset > di + prefix`.
+// out_off[b] = start of block b's output, out_len[b] = its length or -1; the walk
+// stops at the first bad block (later blocks report -1).
+__global__ __launch_bounds__(64) void k_decode4_linked(const uint8_t *__restrict__ src,
+                                                       const uint64_t *__restrict__ off,
+                                                       const uint32_t *__restrict__ sw, size_t nb,
+                                                       uint8_t *dst, uint32_t block_cap,
+                                                       size_t dst_cap,
+                                                       int32_t *__restrict__ out_len,
+                                                       uint64_t *__restrict__ out_off) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kStage + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t ibuf[kIn + 16];
+    __shared__ uint2 desc[kWave];
+    const int lane = lane_id();
+    size_t total = 0;
+    bool dead = false;
+    for (size_t b = 0; b < nb; b++) {
+        int r = -1;
+        if (!dead) {
+            const uint32_t w = sw[b];
+            const int n = (int)(w & 0x7FFFFFFFu);
+            const uint8_t *in = src + off[b];
+            uint8_t *d = dst + total;
+            // never past the stream buffer: the block's room is what is left of it
+            const size_t left = dst_cap - total;
+            const uint32_t cap = left < block_cap ? (uint32_t)left : block_cap;
+            if (w >> 31) {
+                r = (uint32_t)n > cap ? (int)cap : n;
+                if ((uint32_t)n > cap && cap < block_cap) r = -1;  // cut by the buffer, not by the block size
+                else wave_copy(d, in, r, lane);
+            } else if (n == 0) {
+                r = 0;
+            } else {
+                const int prefix = total > (size_t)kWinSize ? kWinSize : (int)total;
+                r = decode4_block(in, n, d, (int)cap, prefix, lane, stage, ibuf, desc);
+            }
+            r = (int)rfl((uint32_t)r);
+            // this wave's stores must be visible to its own later loads
+            __threadfence();
+        }
+        if (lane == 0) {
+            out_len[b] = r;
+            out_off[b] = total;
+        }
+        if (r < 0) dead = true;
+        else total += (size_t)r;
+    }
+}
+
+hipError_t launch_decode_linked(const uint8_t *src, const uint64_t *off, const uint32_t *sw,
+                                size_t nb, uint8_t *dst, uint32_t block_cap, size_t dst_cap,
+                                int32_t *out_len, uint64_t *out_off, hipStream_t st) {
     if (nb == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_decode, dim3((unsigned)nb), dim3(kWave), 0, st, src, off, sw, nb, dst,
+    hipLaunchKernelGGL(k_decode4_linked, dim3(1), dim3(kWave), 0, st, src, off, sw, nb, dst,
+                       block_cap, dst_cap, out_len, out_off);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode(const uint8_t *src, const uint64_t *off, const uint32_t *sw, size_t nb,
+                          uint8_t *dst, size_t dst_stride, uint32_t dst_len, uint32_t prefix,
+                          int32_t *out_len, hipStream_t st) {
+    if (nb == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_decode4, dim3((unsigned)nb), dim3(kWave), 0, st, src, off, sw, nb, dst,
                        dst_stride, dst_len, prefix, out_len);
     return hipGetLastError();
 }

@@ -1,166 +1,434 @@
-// fast.hip -- Fast (greedy) LZ4 block compressor for gfx950.
+// fast3.hip -- window-parallel Fast LZ4 compressor, generation 3.
 //
-// Restates (*Compressor).CompressBlock, internal/lz4block/block.go:105-295, with
-// the same hash (block.go:35-38), the same 65536 x u16 table and the same
-// get/put order, so the parse -- and therefore every output byte -- is the
-// reference's.  One wavefront per independent block:
-//   * the table lives in LDS (128 KiB; an all-zero table is the reference's
-//     "inUse bitmap cleared" state, block.go:74-94);
-//   * the greedy walk is wave-uniform; match extension (backward and forward),
-//     literal copies and length runs are done 64 lanes wide.
-#include "common.h"
+// Same parse and bytes as (*Compressor).CompressBlock
+// (internal/lz4block/block.go:105-295).  Phase A is fast2's (64 lanes hash, gather
+// the table, verify, pre-extend).  What changes is the serial part:
+//
+//   Phase B, the wave-uniform walk, now only decides WHERE matches are: per match
+//   it costs a handful of scalar operations (find the lane, read its forward
+//   length, move si/anchor, note the puts).  It records the anchor into the match
+//   lane (v_writelane) instead of emitting anything.
+//
+//   Phase C, at window close, encodes ALL sequences of the window at once: every
+//   match lane derives literal/match lengths (backward extension clamped by the
+//   recorded anchor, block.go:170-177), a wave scan of the encoded sizes gives each
+//   sequence its place in dst, one comparison decides the dst-capacity outcome
+//   (every check of block.go:196-245 guards a byte inside the sequence's extent,
+//   so they all pass iff the extents fit), and the lanes write token, lengths,
+//   literals and offset themselves.
+//
+// The scalar unit was the busiest part of generation 2 (14.6 SALU instructions
+// per input byte, profiles/r1_v1_pmc_fast2_summary.txt); this moves the per-
+// sequence work to the vector lanes.
+#include "fast_common.h"
 
 namespace lz4hip {
 
-// (*Compressor).get, block.go:74-86, on a zero-initialised table.
-__device__ __forceinline__ int fast_get(const uint16_t *table, uint32_t h, int si) {
-    int i = (int)table[h] + (si & ~kWinMask);
-    if (i >= si) i -= kWinSize;
-    return i;
+#ifndef LZ4HIP_SRCBUF
+#define LZ4HIP_SRCBUF 1024
+#endif
+#ifndef LZ4HIP_OUTBUF
+#define LZ4HIP_OUTBUF 512
+#endif
+constexpr int kSrcBuf = LZ4HIP_SRCBUF;   // LDS bytes of buffered source per wave
+constexpr int kSrcReach = 84;   // phase A reads s[wbase-8, wbase+84)
+constexpr int kOutBuf = LZ4HIP_OUTBUF;   // LDS bytes in which a window's sequences are assembled (0: none)
+constexpr int kInUseWords = (1 << 16) / 32;  // block.go:57: inUse [1<<16/32]uint32
+
+// Lane `l` of `old` takes the wave-uniform value `v` (v_cmp + v_cndmask: the VOP3
+// form of v_writelane_b32 cannot take two SGPR operands on gfx9).
+#define wrlane(old, v, l) ((lane == (l)) ? (v) : (old))
+
+// Lane-private exact copy (no over-read): literals of one sequence.
+__device__ __forceinline__ void lane_copy_exact(uint8_t *dst, const uint8_t *src, int len) {
+    while (len >= 8) {
+        const uint64_t a = ld64(src);
+        __builtin_memcpy(dst, &a, 8);
+        dst += 8;
+        src += 8;
+        len -= 8;
+    }
+    if (len & 4) {
+        const uint32_t a = ld32(src);
+        __builtin_memcpy(dst, &a, 4);
+        dst += 4;
+        src += 4;
+    }
+    if (len & 2) {
+        uint16_t a;
+        __builtin_memcpy(&a, src, 2);
+        __builtin_memcpy(dst, &a, 2);
+        dst += 2;
+        src += 2;
+    }
+    if (len & 1) *dst = *src;
 }
 
-// Candidate test of block.go:141,151,157.
-__device__ __forceinline__ bool fast_ok(const uint8_t *s, int pos, int ref, uint32_t word) {
-    const int offset = pos - ref;
-    return offset > 0 && offset < kWinSize && word == ld32(s + ref);
+// Lane-private "length - 15" run (block.go:211-219,239-246); returns bytes written.
+__device__ __forceinline__ int lane_len_tail(uint8_t *p, int v) {
+    int k = 0;
+    while (v >= 255) {
+        p[k++] = 0xFF;
+        v -= 255;
+    }
+    p[k++] = (uint8_t)v;
+    return k;
 }
 
-// One block, one wavefront.  `table` is 65536 x u16, zeroed by the caller's wave here;
-// it may live in LDS or in global memory (same-wave accesses are ordered either way).
-template <typename TablePtr>
-__device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const int n,
-                                          uint8_t *__restrict__ d, const int dlen,
-                                          TablePtr table, const int lane) {
+// Exact-length global store of the low `len` (< 8) bytes of v.
+__device__ __forceinline__ void store_tail8(uint8_t *p, uint64_t v, int len) {
+    if (len & 4) {
+        const uint32_t w = (uint32_t)v;
+        __builtin_memcpy(p, &w, 4);
+        p += 4;
+        v >>= 32;
+    }
+    if (len & 2) {
+        const uint16_t w = (uint16_t)v;
+        __builtin_memcpy(p, &w, 2);
+        p += 2;
+        v >>= 16;
+    }
+    if (len & 1) *p = (uint8_t)v;
+}
+
+__device__ __forceinline__ int len_tail_size(int len) {  // bytes after the token for `len`
+    return len >= 0xF ? 1 + (len - 0xF) / 255 : 0;
+}
+
+template <bool kGlobal, typename TablePtr>
+__device__ __forceinline__ int fast3_block(const uint8_t *__restrict__ s, const int n,
+                                           uint8_t *__restrict__ d, const int dlen,
+                                           TablePtr table, uint32_t *tag, uint8_t *sbuf,
+                                           uint8_t *obuf, uint32_t *inuse, const int lane) {
     const int bound = (int)compress_bound32((uint32_t)n);
     const bool not_compressible = dlen < bound;  // block.go:110
     {  // reset(): block.go:94,107
-        uint4 *t4 = (uint4 *)(table);
-        for (int k = lane; k < (1 << 16) * 2 / 16; k += kWave) t4[k] = make_uint4(0, 0, 0, 0);
+        if (kGlobal) {
+            // the reference's own scheme: clear the in-use bitmap (8 KiB, here in LDS), not the
+            // table.  A get() of an unused slot is answered from the bitmap -- table value 0,
+            // block.go:74-79 -- without touching memory, and the table is never zeroed.
+            for (int k = lane; k < kInUseWords; k += kWave) inuse[k] = 0u;
+        } else {  // LDS table: an all-zero table is the cleared-bitmap state
+            typedef uint4 __attribute__((may_alias)) uint4_a;
+            uint4_a *t4 = (uint4_a *)(table);
+            for (int k = lane; k < (1 << 16) * 2 / 16; k += kWave) t4[k] = make_uint4(0, 0, 0, 0);
+        }
+        for (int k = lane; k < kTagN; k += kWave) tag[k] = 0xFFFFFFFFu;
     }
     __syncthreads();
 
     int si = 0, di = 0, anchor = 0;
     const int sn = n - kMfLimit;
-    int ret = 0;
-    bool failed = false;  // ErrInvalidSourceShortBuffer raised
+    bool failed = false, finished = false, pending = false;
+    // The window's own source bytes -- s[wbase-8, wbase+84) -- are read through an
+    // LDS buffer holding s[sb, se), refilled with one coalesced load every ~40
+    // windows: the sequential part of the input costs no global round trip per window.
+    int sb = 0, se = 0;
 
-    while (si < sn) {
-        const uint64_t match = ld64(s + si);
-        const uint32_t h0 = hash6(match);
-        const uint32_t h1 = hash6(match >> 8);
-        // both gets precede both puts: block.go:134-137
-        const int ref0 = fast_get(table, h0, si);
-        const int ref1 = fast_get(table, h1, si + 1);
-        table[h0] = (uint16_t)si;
-        table[h1] = (uint16_t)(si + 1);
-
-        int found, ref;
-        if (fast_ok(s, si, ref0, (uint32_t)match)) {
-            found = si;
-            ref = ref0;
-        } else {
-            const uint32_t h2 = hash6(match >> 16);
-            const int ref2 = fast_get(table, h2, si + 2);  // sees the two puts: :145
-            if (fast_ok(s, si + 1, ref1, (uint32_t)(match >> 8))) {
-                found = si + 1;
-                ref = ref1;
-            } else {
-                table[h2] = (uint16_t)(si + 2);  // :155
-                if (fast_ok(s, si + 2, ref2, (uint32_t)(match >> 16))) {
-                    found = si + 2;
-                    ref = ref2;
+    while (si < sn && !failed && !finished) {
+        si = (int)rfl((uint32_t)si);
+        di = (int)rfl((uint32_t)di);
+        anchor = (int)rfl((uint32_t)anchor);
+        sb = (int)rfl((uint32_t)sb);
+        se = (int)rfl((uint32_t)se);
+        // ================= Phase A: lane l <-> position wbase + l =================
+        const int wbase = si - 2;  // lane 0 is the position of a pending put(si-2)
+        if (wbase + kSrcReach > se && se < n) {
+            sb = wbase - 8 < 0 ? 0 : (wbase - 8) & ~15;
+            const int cnt = n - sb < kSrcBuf ? n - sb : kSrcBuf;
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int k = lane * 16; k < cnt; k += kWave * 16) {
+                if (k + 16 <= cnt) {
+                    const uint64_t a = ld64(s + sb + k), b = ld64(s + sb + k + 8);
+                    *(uint64_t *)(sbuf + k) = a;
+                    *(uint64_t *)(sbuf + k + 8) = b;
                 } else {
-                    si += 4 + ((si + 2 - anchor) >> kAdaptSkipLog);  // :159
-                    continue;
+                    for (int j = k; j < cnt; j++) sbuf[j] = s[sb + j];
+                }
+            }
+            se = sb + cnt;
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        const uint8_t *sl = sbuf - sb;  // sl[q] == s[q] for sb <= q < se
+        const int p = wbase + lane;
+        const bool valid = p >= 0 && p <= sn + 1;
+        uint64_t x = 0;
+        if (valid) __builtin_memcpy(&x, sl + p, 8);
+        const uint32_t h = hash6(x);
+        uint32_t tv = 0;
+        if (kGlobal) {
+            const bool used = valid && ((inuse[h >> 5] >> (h & 31)) & 1u);
+            if (used) tv = tab_load<kGlobal>(table, h);
+        } else if (valid) {
+            tv = tab_load<kGlobal>(table, h);
+        }
+        const uint32_t slot = h & (kTagN - 1);
+        if (valid) atomicMin(&tag[slot], (uint32_t)lane);
+        __asm__ volatile("" ::: "memory");
+        uint32_t tmin = 0xFFFFFFFFu;
+        if (valid) tmin = tag[slot];
+        __asm__ volatile("" ::: "memory");
+        if (valid) tag[slot] = 0xFFFFFFFFu;
+        const bool cflag = valid && tmin < (uint32_t)lane;  // an earlier lane shares my slot
+
+        int ref = (int)tv + (p & ~kWinMask);
+        if (ref >= p) ref -= kWinSize;
+        int offv = p - ref;  // > 0 by construction
+        const bool offok = valid && offv < kWinSize && ref >= 0;
+        const bool f0ok = offok && p + 12 <= sn;  // stride 0 at p+4 runs iff p+4+8 <= sn
+        const bool f1ok = offok && p + 20 <= sn;
+        const bool bok = offok && ref >= 8;
+        uint32_t cw = 0;
+        uint64_t r0 = 0, q0 = 0, r1 = 0, q1 = 0, rb = 0, qb = 0;
+        if (offok) cw = ld32(s + ref);
+        if (f0ok) {
+            r0 = ld64(s + ref + 4);
+            __builtin_memcpy(&q0, sl + p + 4, 8);
+        }
+        if (f1ok) {
+            r1 = ld64(s + ref + 12);
+            __builtin_memcpy(&q1, sl + p + 12, 8);
+        }
+        if (bok) {
+            rb = ld64(s + ref - 8);
+            __builtin_memcpy(&qb, sl + p - 8, 8);
+        }
+        const bool m4 = offok && cw == (uint32_t)x;
+        int mendv = p + kMinMatch;  // end of the match that starts at p (absolute)
+        bool fmore = false;
+        if (m4 && f0ok) {
+            uint64_t xx = r0 ^ q0;
+            if (xx) {
+                mendv += __builtin_ctzll(xx) >> 3;
+            } else {
+                mendv += 8;
+                if (f1ok) {
+                    xx = r1 ^ q1;
+                    if (xx) {
+                        mendv += __builtin_ctzll(xx) >> 3;
+                    } else {
+                        mendv += 8;
+                        fmore = true;  // still equal after 16 bytes: continue cooperatively
+                    }
                 }
             }
         }
-        const int offset = found - ref;
-
-        // ---- backward extension, block.go:170-177, 64 bytes per round ----
-        int back = 0;
-        {
-            const int l0 = found - anchor;
-            const int maxb = l0 < ref ? l0 : ref;  // lLen > 0 && tOff >= 0
-            while (back < maxb) {
-                const int k = back + lane;
-                const bool eq = k < maxb && s[found - 1 - k] == s[ref - 1 - k];
-                const uint64_t stop = ballot(!eq);
-                if (stop == 0) {
-                    back += kWave;
-                    continue;
+        int backv = 0;  // backward-equal bytes (upper bound; clamped by the anchor later)
+        bool bmore = false;
+        if (m4) {
+            if (bok) {
+                const uint64_t xx = rb ^ qb;
+                if (xx) {
+                    backv = __builtin_clzll(xx) >> 3;
+                } else {
+                    backv = 8;
+                    bmore = true;
                 }
-                back += __builtin_ctzll(stop);
-                break;
+            } else {
+                bmore = true;  // too close to the block start for the 8-byte loads
             }
         }
-        const int m_start = found - back;
-        const int l_len = m_start - anchor;
+        const uint64_t M = ballot(m4), CM = ballot(cflag);
+        const uint64_t SLOW = ballot(fmore || bmore);  // matches that may need more extension
+        const uint64_t ATT = M | CM;                   // lanes that need a look during the walk
+        const uint16_t pos16 = (uint16_t)p;
+        int anch = 0;          // anchor recorded into the match lanes by the walk
+        uint64_t FOUND = 0;    // match lanes of this window
+        uint64_t P = pending ? 1ull : 0ull;  // lanes put() since the snapshot; lane 0 = put(si-2)
+        pending = false;
 
-        // ---- forward extension, block.go:184-193: 8-byte strides while si+8 <= sn ----
-        si = found + kMinMatch;
+        // The next window will gather the table for positions wbase+64.. (unless a long
+        // match jumps over them): touch those lines now, so that the walk below hides
+        // their trip from HBM and the next gather finds them in L2.
+        // ================= Phase B: where are the matches =================
         for (;;) {
-            const int p = si + 8 * lane;
-            const bool valid = p + 8 <= sn;
-            uint64_t x = 0;
-            if (valid) x = ld64(s + p) ^ ld64(s + p - offset);
-            const uint64_t stop = ballot(!valid || x != 0);
-            if (stop == 0) {
-                si += 8 * kWave;
+            si = (int)rfl((uint32_t)si);
+            anchor = (int)rfl((uint32_t)anchor);
+            P = ((uint64_t)rfl((uint32_t)(P >> 32)) << 32) | rfl((uint32_t)P);
+            FOUND = ((uint64_t)rfl((uint32_t)(FOUND >> 32)) << 32) | rfl((uint32_t)FOUND);
+            const int a = si - wbase;
+            if (a > 61 || si >= sn) break;
+            const uint32_t att3 = (uint32_t)(ATT >> a) & 7u;
+            if (att3 == 0) {
+                // three failed probes, three puts (:136-137,155), skip (:159)
+                const int d0 = si + 2 - anchor;
+                if (d0 <= 64 && si + 64 < sn) {
+                    const uint64_t pat = 0x7777777777777777ull << a;  // probed lanes a+4k+{0,1,2}
+                    const uint64_t hot = ATT & pat;
+                    const int kmax = ((61 - a) >> 2) + 1;
+                    int k = hot ? (__builtin_ctzll(hot) - a) >> 2 : kmax;  // clean steps (>= 1)
+                    if (k > kmax) k = kmax;
+                    const int e = a + 4 * k;
+                    P |= e >= 64 ? pat : (pat & ((1ull << e) - 1));
+                    si += 4 * k;
+                } else {
+                    P |= 7ull << a;
+                    si += 4 + (d0 >> kAdaptSkipLog);
+                }
                 continue;
             }
-            const int k = __builtin_ctzll(stop);
-            const uint32_t xlo = (uint32_t)__shfl((int)(uint32_t)x, k);
-            const uint32_t xhi = (uint32_t)__shfl((int)(uint32_t)(x >> 32), k);
-            const uint64_t xk = ((uint64_t)xhi << 32) | xlo;
-            si += 8 * k;
-            if (xk != 0) si += __builtin_ctzll(xk) >> 3;  // lane k was valid and differed
-            break;
+            int f;  // match lane
+            if ((((CM | SLOW) >> a) & 7u) == 0) {
+                // ---- common case: snapshot answers exact, extension complete ----
+                const int j = __builtin_ctz(att3);
+                f = a + j;
+                P |= (j == 2 ? 7ull : 3ull) << a;
+                anch = wrlane(anch, anchor, f);
+                si = (int)rdlane((uint32_t)mendv, f);
+            } else {
+                // ---- rare: a probe may depend on a put of this window, or the match
+                // needs cooperative extension.  Resolve in the reference's order. ----
+                int j = -1, dep_l = -1;
+#pragma unroll
+                for (int t = 0; t < 3 && j < 0; ++t) {
+                    const int b = a + t;
+                    // probes 0,1 see the puts before this step; probe 2 also put(si), put(si+1)
+                    const uint64_t vis = t == 2 ? (P | (3ull << a)) : P;
+                    bool hit = (M >> b) & 1;
+                    int dl = -1;
+                    if ((CM >> b) & 1) {
+                        const uint64_t E = ballot(h == rdlane(h, b)) & vis;
+                        if (E) {
+                            dl = 63 - __builtin_clzll(E);  // the latest put with my hash
+                            hit = rdlane((uint32_t)x, b) == rdlane((uint32_t)x, dl);
+                        }
+                    }
+                    if (hit) {
+                        j = t;
+                        dep_l = dl;
+                    }
+                }
+                if (j < 0) {
+                    P |= 7ull << a;
+                    si += 4 + ((si + 2 - anchor) >> kAdaptSkipLog);
+                    continue;
+                }
+                f = a + j;
+                P |= (j == 2 ? 7ull : 3ull) << a;
+                const int found = si + j;
+                const int l0 = found - anchor;
+                int offset, back, mend;
+                if (dep_l >= 0) {
+                    offset = f - dep_l;
+                    const int mref = found - offset;
+                    const int maxb = l0 < mref ? l0 : mref;
+                    back = ext_backward(s, found, mref, 0, maxb, lane);
+                    mend = ext_forward(s, found + kMinMatch, offset, sn, lane);
+                } else {
+                    offset = (int)rdlane((uint32_t)offv, f);
+                    const int mref = found - offset;
+                    const int maxb = l0 < mref ? l0 : mref;
+                    const int bw = (int)rdlane((uint32_t)backv, f);
+                    back = bw < maxb ? bw : maxb;
+                    mend = (int)rdlane((uint32_t)mendv, f);
+                    const uint32_t fl = rdlane((uint32_t)fmore | ((uint32_t)bmore << 1), f);
+                    if ((fl & 2u) && maxb > bw) back = ext_backward(s, found, mref, bw, maxb, lane);
+                    if (fl & 1u) mend = ext_forward(s, mend, offset, sn, lane);
+                }
+                offv = wrlane(offv, offset, f);
+                backv = wrlane(backv, back, f);
+                mendv = wrlane(mendv, mend, f);
+                anch = wrlane(anch, anchor, f);
+                si = mend;
+            }
+            FOUND |= 1ull << f;
+            anchor = si;
+            if (si >= sn) {  // block.go:250-252
+                finished = true;
+                break;
+            }
+            // put(hash(si-2), si-2): block.go:254-255
+            const int q = si - 2 - wbase;
+            if (q <= 63)
+                P |= 1ull << q;
+            else
+                pending = true;  // lane 0 of the next window
         }
-        int m_len = si - (m_start + kMinMatch);
 
-        // ---- emit, block.go:195-248 ----
-        if (di >= dlen) {
-            failed = true;
-            break;
-        }
-        if (lane == 0)
-            d[di] = (uint8_t)((m_len < 0xF ? m_len : 0xF) | ((l_len < 0xF ? l_len : 0xF) << 4));
-        di++;
-        if (l_len >= 0xF) {
-            di = emit_len_tail(d, di, dlen, l_len - 0xF, lane);
-            if (di < 0) {
+        // ================= Phase C: encode every sequence of the window =================
+        if (FOUND) {
+            const bool mine = (FOUND >> lane) & 1;
+            // block.go:166-182 with the recorded anchor
+            const int l0 = p - anch;
+            const int mref = p - offv;
+            int back = backv;
+            if (back > l0) back = l0;
+            if (back > mref) back = mref;
+            const int m_start = p - back;
+            const int l_len = m_start - anch;
+            const int m_len = mendv - m_start - kMinMatch;
+            const int lt = len_tail_size(l_len), mt = len_tail_size(m_len);
+            const int esz = mine ? 1 + lt + l_len + 2 + mt : 0;
+            const int incl = wave_incl_scan(esz);
+            const int total = (int)rdlane((uint32_t)incl, 63);
+            if (di + total > dlen) {
+                // some byte of some sequence would land at or beyond len(dst):
+                // ErrInvalidSourceShortBuffer (block.go:196-245)
                 failed = true;
-                break;
+            } else {
+                auto emit = [&](uint8_t *o) {
+                    *o++ = (uint8_t)((m_len < 0xF ? m_len : 0xF) | ((l_len < 0xF ? l_len : 0xF) << 4));
+                    if (l_len >= 0xF) o += lane_len_tail(o, l_len - 0xF);
+                    // literals are the bytes just before the match: usually still in sbuf
+                    if (anch >= sb)
+                        lane_copy_exact(o, sl + anch, l_len);
+                    else
+                        lane_copy_exact(o, s + anch, l_len);
+                    o += l_len;
+                    const int ofs = offv;
+                    o[0] = (uint8_t)ofs;
+                    o[1] = (uint8_t)(ofs >> 8);
+                    if (m_len >= 0xF) lane_len_tail(o + 2, m_len - 0xF);
+                };
+                if (kOutBuf > 0 && total <= kOutBuf) {
+                    // The sequences of a window are a few dozen bytes each and contiguous in
+                    // dst: assemble them in LDS and write them out 16 bytes per lane (two or
+                    // three store requests per window instead of a dozen byte-granular ones).
+                    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the last flush has read obuf
+                    if (mine) emit(obuf + (incl - esz));
+                    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    uint8_t *to = d + di;
+                    for (int k = lane * 16; k < total; k += kWave * 16) {
+                        const uint64_t a = *(const uint64_t *)(obuf + k), b = *(const uint64_t *)(obuf + k + 8);
+                        const int rem = total - k;
+                        if (rem >= 16) {
+                            __builtin_memcpy(to + k, &a, 8);
+                            __builtin_memcpy(to + k + 8, &b, 8);
+                        } else if (rem >= 8) {
+                            __builtin_memcpy(to + k, &a, 8);
+                            store_tail8(to + k + 8, b, rem - 8);
+                        } else {
+                            store_tail8(to + k, a, rem);
+                        }
+                    }
+                } else if (mine) {
+                    emit(d + di + (incl - esz));
+                }
+                di += total;
             }
         }
-        if (di + l_len > dlen) {
-            failed = true;
-            break;
-        }
-        wave_copy(d + di, s + anchor, l_len, lane);
-        di += l_len + 2;
-        anchor = si;
-        if (di > dlen) {
-            failed = true;
-            break;
-        }
-        if (lane == 0) {
-            d[di - 2] = (uint8_t)offset;
-            d[di - 1] = (uint8_t)(offset >> 8);
-        }
-        if (m_len >= 0xF) {
-            di = emit_len_tail(d, di, dlen, m_len - 0xF, lane);
-            if (di < 0) {
-                failed = true;
-                break;
+
+        // ---- close the window: write this window's puts to the table ----
+        if (!failed && !finished) {
+            if ((P & ~CM) >> lane & 1) table[h] = pos16;  // distinct slots: one store
+            uint64_t Pd = P & CM;  // may share a slot with an earlier put: position order
+            while (Pd) {
+                __asm__ volatile("" ::: "memory");
+                const int l = __builtin_ctzll(Pd);
+                Pd &= Pd - 1;
+                if (lane == l) table[h] = pos16;
             }
+            __asm__ volatile("" ::: "memory");
+            if (kGlobal && ((P >> lane) & 1)) atomicOr(&inuse[h >> 5], 1u << (h & 31));
+            __asm__ volatile("" ::: "memory");
         }
-        if (si >= sn) break;                                   // :250-252
-        table[hash6(ld64(s + si - 2))] = (uint16_t)(si - 2);  // :254-255
     }
 
-    // ---- last literals, block.go:258-294 ----
+    // ---------------- last literals: block.go:258-294 ----------------
+    di = (int)rfl((uint32_t)di);
+    anchor = (int)rfl((uint32_t)anchor);
+    int ret;
     if (failed) {
         ret = -1;
     } else if (not_compressible && anchor == 0) {
@@ -186,62 +454,84 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
     return ret;
 }
 
-__device__ __forceinline__ int block_dlen(int dst_mode, int n, uint32_t dst_len_x) {
-    return dst_mode == LZ4HIP_DST_FRAME  ? n
-           : dst_mode == LZ4HIP_DST_BOUND ? (int)compress_bound32((uint32_t)n)
-                                          : (int)dst_len_x;
-}
-
-// Variant A: table in LDS, one workgroup (= one wave) per block, one block per CU.
-__global__ __launch_bounds__(64) void k_fast_compress(const uint8_t *__restrict__ src,
-                                                      size_t n_total, uint32_t block_size,
-                                                      int dst_mode, uint32_t dst_len_x,
-                                                      uint8_t *__restrict__ dst,
-                                                      size_t dst_stride,
-                                                      int32_t *__restrict__ result) {
+// Table in LDS: one wave (= one workgroup) per block, one block per CU.
+__global__ __launch_bounds__(64) void k_fast3_lds(const uint8_t *__restrict__ src, size_t n_total,
+                                                  uint32_t block_size, int dst_mode,
+                                                  uint32_t dst_len_x, uint8_t *__restrict__ dst,
+                                                  size_t dst_stride,
+                                                  int32_t *__restrict__ result) {
     __shared__ uint16_t table[1 << 16];
+    __shared__ uint32_t tag[kTagN];
+    __shared__ __attribute__((aligned(16))) uint8_t sbuf[kSrcBuf];
+    __shared__ __attribute__((aligned(16))) uint8_t obuf[kOutBuf + 16];
     const int lane = lane_id();
     const size_t b = blockIdx.x;
     const size_t start = b * (size_t)block_size;
     const size_t left = n_total > start ? n_total - start : 0;
     const int n = (int)(left < block_size ? left : block_size);
-    const int r = fast_block(src + start, n, dst + b * dst_stride,
-                             block_dlen(dst_mode, n, dst_len_x), table, lane);
+    const int r = fast3_block<false>(src + start, n, dst + b * dst_stride,
+                                     block_dlen2(dst_mode, n, dst_len_x), table, tag, sbuf, obuf,
+                                     nullptr, lane);
     if (lane == 0) result[b] = r;
 }
 
-// Variant B: table in a global-memory slot per resident wave (stays in L2 / the
-// Infinity Cache), many waves per CU hide the dependent-load latency of the walk.
-__global__ __launch_bounds__(64) void k_fast_compress_gtab(const uint8_t *__restrict__ src,
-                                                           size_t n_total, uint32_t block_size,
-                                                           size_t nb, int dst_mode,
-                                                           uint32_t dst_len_x,
-                                                           uint8_t *__restrict__ dst,
-                                                           size_t dst_stride,
-                                                           int32_t *__restrict__ result,
-                                                           uint16_t *__restrict__ ws) {
+// Table in a global-memory slot per resident wave; many waves per CU.
+__global__ __launch_bounds__(64) void k_fast3_gtab(const uint8_t *__restrict__ src, size_t n_total,
+                                                   uint32_t block_size, size_t nb, int dst_mode,
+                                                   uint32_t dst_len_x, uint8_t *__restrict__ dst,
+                                                   size_t dst_stride,
+                                                   int32_t *__restrict__ result,
+                                                   uint16_t *__restrict__ ws,
+                                                   uint32_t *__restrict__ next_block) {
+    __shared__ uint32_t tag[kTagN];
+    __shared__ __attribute__((aligned(16))) uint8_t sbuf[kSrcBuf];
+    __shared__ __attribute__((aligned(16))) uint8_t obuf[kOutBuf + 16];
+    __shared__ uint32_t inuse[kInUseWords];
     const int lane = lane_id();
     uint16_t *table = ws + (size_t)blockIdx.x * (1 << 16);
-    for (size_t b = blockIdx.x; b < nb; b += gridDim.x) {
+    // Blocks cost very different amounts of time (incompressible ones a fraction of
+    // text), so a wave takes its next block from a shared counter when it finishes one
+    // (goroutines pulling from the Writer's channel do the same, writer.go:130-142);
+    // without a counter the blocks are dealt round-robin.
+    auto take = [&]() -> size_t {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(next_block, 1u);
+        return (size_t)rfl(t);
+    };
+    // with the counter even the first block is taken from it: a workgroup that only gets a
+    // CU once others have finished must not sit on a block dealt to it in advance
+    size_t b = next_block ? take() : (size_t)blockIdx.x;
+    while (b < nb) {
         const size_t start = b * (size_t)block_size;
         const size_t left = n_total > start ? n_total - start : 0;
         const int n = (int)(left < block_size ? left : block_size);
-        const int r = fast_block(src + start, n, dst + b * dst_stride,
-                                 block_dlen(dst_mode, n, dst_len_x), table, lane);
+        const int r = fast3_block<true>(src + start, n, dst + b * dst_stride,
+                                                   block_dlen2(dst_mode, n, dst_len_x), table, tag,
+                                                   sbuf, obuf, inuse, lane);
         if (lane == 0) result[b] = r;
+        __syncthreads();
+        if (next_block)
+            b = take();
+        else
+            b += gridDim.x;
     }
 }
 
 hipError_t launch_fast(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
-                       uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,
-                       uint16_t *ws, size_t slots, hipStream_t st) {
+                        uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,
+                        uint16_t *ws, size_t slots, uint32_t *next_block, hipStream_t st) {
     if (nb == 0) return hipSuccess;
     if (ws && slots) {
         const size_t grid = nb < slots ? nb : slots;
-        hipLaunchKernelGGL(k_fast_compress_gtab, dim3((unsigned)grid), dim3(kWave), 0, st, src, n,
-                           bs, nb, dst_mode, dst_len_x, dst, dst_stride, result, ws);
+        if (grid == nb) next_block = nullptr;  // every block has a wave of its own
+        if (next_block) {
+            const hipError_t e = hipMemsetAsync(next_block, 0, sizeof(uint32_t), st);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(k_fast3_gtab, dim3((unsigned)grid), dim3(kWave), 0, st, src, n, bs, nb,
+                           dst_mode, dst_len_x, dst, dst_stride, result, ws, next_block);
     } else {
-        hipLaunchKernelGGL(k_fast_compress, dim3((unsigned)nb), dim3(kWave), 0, st, src, n, bs,
+        hipLaunchKernelGGL(k_fast3_lds, dim3((unsigned)nb), dim3(kWave), 0, st, src, n, bs,
                            dst_mode, dst_len_x, dst, dst_stride, result);
     }
     return hipGetLastError();

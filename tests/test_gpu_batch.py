@@ -361,19 +361,3 @@ def test_hc_block_schedule(T, oracle, tail):
                 assert res_h[b] <= 0, b
             else:
                 assert res_h[b] == size and comp_h[b, :size].tobytes() == pl[b, :size].tobytes(), b
-
-
-@pytest.mark.parametrize("gen", ["1", "2", "4"])
-def test_fast_other_generations(T, oracle, gen, monkeypatch):
-    """LZ4HIP_FAST selects the older / experimental Fast kernels (read per call):
-    every generation must emit the oracle's bytes.  4 = one lane per block."""
-    from lz4_amd import corpus, device as dev
-    monkeypatch.setenv("LZ4HIP_FAST", gen)
-    monkeypatch.setattr(dev, "_ws_cache", {})
-    bs = 1 << 16
-    data = corpus.generate("mixed", 99, 1300 * bs + 4321)
-    _check_blocks(T, oracle, data, bs)
-    if gen == "4":  # ragged sizes, bound mode and tiny blocks through the lane kernel
-        data = corpus.generate("binary", 5 << 20, 1030 * (1 << 18) + 13)
-        _check_blocks(T, oracle, data, 1 << 18)
-    monkeypatch.setattr(dev, "_ws_cache", {})

@@ -63,42 +63,6 @@ def test_fuzz_corpus_matches_oracle_and_stays_in_bounds(oracle):
             assert (buf[size:] == (np.arange(size, size + 8) & 0xFF)).all(), name
 
 
-@pytest.mark.parametrize("gen", ["1", "2", "3"])
-def test_older_decoder_generations(gen, oracle, monkeypatch):
-    """LZ4HIP_DECODE selects the older decode kernels (read per call; 4 is the default):
-    each must give the known answers, reject the invalid inputs inside bounds and
-    round-trip a mixed corpus."""
-    import torch
-    import lz4_amd as lz
-    from lz4_amd import corpus, device as dev
-    monkeypatch.setenv("LZ4HIP_DECODE", gen)
-    for name, src, exp in kats.DECODE:
-        dst = np.zeros(len(exp), dtype=np.uint8)
-        assert lz.UncompressBlock(src, dst) == len(exp), name
-        assert dst.tobytes() == exp, name
-    for name, src, size in kats.INVALID:
-        if src == b"":
-            continue
-        buf = (np.arange(size + 8) & 0xFF).astype(np.uint8)
-        with pytest.raises(lz.ErrInvalidSourceShortBuffer):
-            lz.UncompressBlock(src, buf[:size])
-        assert (buf[size:] == (np.arange(size, size + 8) & 0xFF)).all(), name
-    bs = 1 << 16
-    data = corpus.generate("mixed", 31, 40 * bs + 321)
-    src = torch.zeros(data.size + 16, dtype=torch.uint8, device="cuda")
-    src[:data.size] = torch.from_numpy(data).cuda()
-    src = src[:data.size]
-    comp, res = dev.compress_blocks(src, bs, 0)
-    nb = res.numel()
-    off, sw = dev.frame_layout(res, data.size, bs, nb)
-    packed = torch.zeros(int(off[nb].item()) + 16, dtype=torch.uint8, device="cuda")
-    dev.frame_scatter(src, bs, comp, res, off, nb, packed)
-    out, ol = dev.uncompress_blocks(packed, (off[:nb] + 4).contiguous(), sw, bs)
-    ol = ol.cpu().numpy()
-    flat = np.concatenate([out[b, :ol[b]].cpu().numpy() for b in range(nb)])
-    assert flat.tobytes() == data.tobytes()
-
-
 @pytest.mark.parametrize("want,data", kats.XXH32)
 def test_xxh32_kat(want, data):
     import lz4_amd as lz
