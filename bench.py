@@ -203,7 +203,7 @@ def main():
         traffic, ra = None, None
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                tj = json.load(f)["k_fast3_gtab"]
+                tj = json.load(f)["k_fast_gtab"]
             traffic = round(tj["traffic_bytes_per_byte"] * n)
             req = (tj["read_requests_per_byte"] + tj["write_requests_per_byte"]) * n
             ra = {"achieved_Greq_s": round(req / t_comp / 1e9, 2), "peak_Greq_s": RANDOM_RW_PEAK_GREQ,
@@ -237,7 +237,7 @@ def main():
             "decompress_GBps": round(n / t_dec / 1e9, 3),
             "kernel_ms": {"fast_compress": round(t_comp * 1e3, 3), "xxh32_blocks": round(t_xxh * 1e3, 3),
                           "decode": round(t_dec * 1e3, 3)},
-            "roofline": {"bound": "hbm", "kernel": "k_fast3_gtab",
+            "roofline": {"bound": "hbm", "kernel": "k_fast_gtab",
                          "achieved": round(alg_bytes / t_comp / 1e9, 3), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(alg_bytes / t_comp / 1e9 / HBM_PEAK_GBPS, 5),
                          "traffic": traffic, "random_access": ra,

@@ -42,6 +42,12 @@ extern "C" {
 #define LZ4HIP_ERR_BLOCK_CHECKSUM (-7)  /* ErrInvalidBlockChecksum */
 #define LZ4HIP_ERR_FRAME_CHECKSUM (-8)  /* ErrInvalidFrameChecksum */
 #define LZ4HIP_ERR_BLOCK (-9)           /* ErrInvalidSourceShortBuffer inside a frame */
+/* The single-block host entry points return the Go convention n / 0 / -1, where -1 is the
+ * CODEC's verdict (ErrInvalidSourceShortBuffer).  A failure of the call itself is never
+ * folded into it: LZ4HIP_ERR_HIP (-2) for a HIP runtime failure, LZ4HIP_ERR_BADARG for a
+ * bad argument.  A binding must surface those as real errors: in the frame step an
+ * "error" from the block compressor means "store the block raw" (lz4stream/block.go:238-245). */
+#define LZ4HIP_ERR_BADARG (-10)
 
 /* Block sizes: internal/lz4block/blocks.go:6-12 (lz4.go:16-24 asserts equality). */
 #define LZ4HIP_BLOCK_64KB (1u << 16)
@@ -71,6 +77,15 @@ extern "C" {
 const char *lz4hip_last_error(void);          /* thread-local text of the last failure */
 int lz4hip_device_count(void);                /* GPUs visible; 0 if none */
 const char *lz4hip_version(void);
+
+/* Optional process set-up for the host-pointer entry points, the counterpart of the
+ * reference's sync.Pools (internal/lz4block/block.go:96,310, blocks.go:42-87): device
+ * memory freed by a call stays in the device's stream-ordered pool instead of going back
+ * to the driver, so the next call's buffers (source, slots, frame, the 384 MiB Fast
+ * workspace) cost no driver allocation.  device < 0: every visible GPU.  lz4hip_shutdown
+ * trims the pools again.  Both return LZ4HIP_OK or LZ4HIP_ERR_HIP. */
+int lz4hip_init(int device);
+int lz4hip_shutdown(void);
 
 /* lz4.CompressBlockBound: lz4.go:27-29, internal/lz4block/block.go:40-42. Host only. */
 size_t lz4hip_compress_bound(size_t n);
@@ -113,11 +128,17 @@ int lz4hip_compress_hc_blocks(const void *d_src, size_t n, uint32_t block_size, 
  * FrameDataBlock.Uncompress, lz4stream/block.go:319-329.
  * Block b's input is d_src + d_src_off[b], length d_size_words[b] & 0x7fffffff;
  * bit 31 set means stored raw (copied).  Output goes to d_dst + b*dst_stride,
- * at most dst_len bytes.  A zero-length compressed input yields 0 (block.go:45-47). */
-int lz4hip_uncompress_blocks(const void *d_src, const uint64_t *d_src_off,
+ * at most dst_len bytes.  A zero-length compressed input yields 0 (block.go:45-47).
+ * d_src holds src_len bytes: a block whose d_src_off[b] + length passes src_len is
+ * rejected on the device (d_out_len[b] = -1) without reading it.
+ * d_dict / dict_len (may be NULL / 0): lz4.UncompressBlockWithDict (lz4.go:47-49,
+ * decode_other.go:109-121) -- every block of the batch decodes against the same
+ * dictionary, of which the last 64 KiB are reachable; a match that starts before the
+ * block's own output reads the dictionary's tail and continues in the output. */
+int lz4hip_uncompress_blocks(const void *d_src, size_t src_len, const uint64_t *d_src_off,
                              const uint32_t *d_size_words, size_t n_blocks, void *d_dst,
-                             size_t dst_stride, uint32_t dst_len, int32_t *d_out_len,
-                             void *stream);
+                             size_t dst_stride, uint32_t dst_len, const void *d_dict,
+                             size_t dict_len, int32_t *d_out_len, void *stream);
 
 /* xxh32.ChecksumZero per block: internal/xxh32/xxh32zero.go:142-184, as used for
  * block checksums over UNCOMPRESSED bytes, lz4stream/block.go:248-250,330-335.
@@ -188,8 +209,11 @@ int64_t lz4hip_compress_block_hc(const uint8_t *src, size_t n, uint8_t *dst, siz
 /* lz4.UncompressBlock / UncompressBlockWithDict: lz4.go:37-49. */
 int64_t lz4hip_uncompress_block(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_len,
                                 const uint8_t *dict, size_t dict_len);
-/* xxh32.ChecksumZero: internal/xxh32/xxh32zero.go:142. */
+/* xxh32.ChecksumZero: internal/xxh32/xxh32zero.go:142.  lz4hip_xxh32 returns 0 when the
+ * call itself fails, which a real checksum can also be: lz4hip_xxh32_checked returns
+ * LZ4HIP_OK / LZ4HIP_ERR_HIP / LZ4HIP_ERR_BADARG and stores the checksum in *out. */
 uint32_t lz4hip_xxh32(const uint8_t *p, size_t n);
+int lz4hip_xxh32_checked(const uint8_t *p, size_t n, uint32_t *out);
 
 /* Writer.Write(src)+Close(), or io.Copy(zw, src) with LZ4HIP_F_READFROM:
  * writer.go:74-145,173-184,199-242.  level 0 = Fast, else HC depth.
@@ -217,6 +241,52 @@ int64_t lz4hip_frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size
  * receives the number of blocks decoded, which may exceed max_blocks. */
 int64_t lz4hip_frame_uncompress_lens(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_cap,
                                      uint32_t *block_lens, size_t max_blocks, size_t *n_blocks);
+
+/* ------------------------------------------------------------------------
+ * Streaming batches: what Writer.Write / Reader.Read bind when ConcurrencyOption(n)
+ * is set (writer.go:123-145, internal/lz4stream/block.go:21-58,95-185).  The
+ * reference fans n blocks out to goroutines and an ordered writer / collector puts
+ * them back in stream order; here the n blocks are ONE call, the frame header and
+ * trailer stay with the caller (Frame.InitW / CloseW, frame.go:46-74), and memory is
+ * bounded by n blocks however long the stream is.
+ * A handle is the per-frame state: the XXHZero content checksum (Frame.checksum,
+ * frame.go:27; on the host) and device buffers + a HIP stream sized for max_blocks
+ * blocks, allocated once (the reference pools its block buffers, blocks.go:42-87).
+ * A handle belongs to one Writer or one Reader; calls on one handle do not overlap.
+ * flags: LZ4HIP_F_BLOCK_CHECKSUM | LZ4HIP_F_CONTENT_CHECKSUM | LZ4HIP_F_LEGACY
+ * (write side only); level: 0 = Fast, else the HC depth (write side only).
+ * Returns NULL on failure (lz4hip_last_error()).
+ * ---------------------------------------------------------------------- */
+typedef struct lz4hip_stream lz4hip_stream;
+lz4hip_stream *lz4hip_stream_create(uint32_t block_size, uint32_t flags, uint32_t level,
+                                    size_t max_blocks);
+void lz4hip_stream_destroy(lz4hip_stream *s);
+/* Writer.Reset / Reader.Reset -> Frame.Reset: checksum.Reset() (frame.go:35-44). */
+void lz4hip_stream_reset(lz4hip_stream *s);
+/* Frame.checksum.Sum32() for CloseW / CloseR (frame.go:69-71,125). */
+uint32_t lz4hip_stream_checksum(const lz4hip_stream *s);
+/* FrameDataBlock.Compress + Write for up to max_blocks blocks (lz4stream/block.go:224-276):
+ * src is cut every block_size bytes (the last block may be short; n == 0 is the one empty
+ * block of writer.go:220-233).  dst receives, in stream order, "u32 size | data | [u32
+ * checksum]" per block -- the bytes the ordered writer goroutine would have written -- and
+ * src is folded into the content checksum.  dst_cap >= n + 8 * n_blocks.  block_lens (may
+ * be NULL): len(block.Data) per block, for OnBlockDoneOption (writer.go:127).
+ * Returns the bytes written to dst or a negative LZ4HIP_ERR_*. */
+int64_t lz4hip_stream_compress_blocks(lz4hip_stream *s, const uint8_t *src, size_t n, uint8_t *dst,
+                                      size_t dst_cap, uint32_t *block_lens);
+/* FrameDataBlock.Read + Uncompress for a run of blocks (lz4stream/block.go:279-340; standard
+ * frames with independent blocks -- the reference drops to serial for linked ones,
+ * reader.go:86-90).  src[0..n) starts at a size word.  Up to max_blocks entries that are
+ * COMPLETE in src are decoded into dst in stream order, block checksums verified on the
+ * decoded bytes, the output folded into the content checksum.  *consumed = bytes of src
+ * used; *end_mark = 1 when the end mark (size word 0) was reached and consumed -- the content
+ * checksum word that may follow it is the caller's to read and compare with
+ * lz4hip_stream_checksum().  block_lens / n_blocks (may be NULL): decoded length per block.
+ * Returns the decoded bytes or a negative LZ4HIP_ERR_* (the first failing block in stream
+ * order decides, lz4stream/block.go:187-194). */
+int64_t lz4hip_stream_uncompress_blocks(lz4hip_stream *s, const uint8_t *src, size_t n, uint8_t *dst,
+                                        size_t dst_cap, size_t *consumed, int *end_mark,
+                                        uint32_t *block_lens, size_t *n_blocks);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("LZ4HIP_LIB") or os.path.join(_HERE, "liblz4hip.so")
 # status codes of include/lz4hip.h
 OK, ERR_ARG, ERR_HIP, ERR_SHORT, ERR_FRAME = 0, -1, -2, -3, -4
 ERR_HEADER_CHECKSUM, ERR_BLOCK_SIZE, ERR_BLOCK_CHECKSUM, ERR_FRAME_CHECKSUM, ERR_BLOCK = -5, -6, -7, -8, -9
+ERR_BADARG = -10  # single-block host calls: bad argument (-1 is the codec's verdict there)
 
 DST_FRAME, DST_BOUND = 0, 1
 F_BLOCK_CHECKSUM, F_CONTENT_CHECKSUM, F_CONTENT_SIZE, F_READFROM, F_LEGACY, F_LINKED = 1, 2, 4, 8, 16, 32
@@ -28,7 +29,16 @@ SYMBOLS = {
     "lz4hip_compress_fast_blocks": (_int, [_vp, _sz, _u32, _int, _vp, _sz, _vp, _vp, _sz, _vp]),
     "lz4hip_hc_workspace_bytes": (_sz, [_sz]),
     "lz4hip_compress_hc_blocks": (_int, [_vp, _sz, _u32, _u32, _int, _vp, _sz, _vp, _vp, _sz, _vp]),
-    "lz4hip_uncompress_blocks": (_int, [_vp, _vp, _vp, _sz, _vp, _sz, _u32, _vp, _vp]),
+    "lz4hip_uncompress_blocks": (_int, [_vp, _sz, _vp, _vp, _sz, _vp, _sz, _u32, _vp, _sz, _vp, _vp]),
+    "lz4hip_init": (_int, [_int]),
+    "lz4hip_shutdown": (_int, []),
+    "lz4hip_xxh32_checked": (_int, [_vp, _sz, _vp]),
+    "lz4hip_stream_create": (_vp, [_u32, _u32, _u32, _sz]),
+    "lz4hip_stream_destroy": (None, [_vp]),
+    "lz4hip_stream_reset": (None, [_vp]),
+    "lz4hip_stream_checksum": (_u32, [_vp]),
+    "lz4hip_stream_compress_blocks": (_i64, [_vp, _vp, _sz, _vp, _sz, _vp]),
+    "lz4hip_stream_uncompress_blocks": (_i64, [_vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
     "lz4hip_xxh32_blocks": (_int, [_vp, _sz, _sz, _vp, _vp, _sz, _vp, _vp]),
     "lz4hip_xxh32_stream": (_int, [_vp, _sz, _vp, _vp]),
     "lz4hip_xxh32_stream_update": (_int, [_vp, _sz, _vp, _int, _int, _vp, _vp]),

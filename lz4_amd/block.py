@@ -85,9 +85,14 @@ def UncompressBlockWithDict(src, dst, dict):
 
 def ChecksumZero(data):
     """xxh32.ChecksumZero (internal/xxh32/xxh32zero.go:142)."""
+    import ctypes
     _lib.require_gpu()
     a = _ro(data)
-    return _lib.load().lz4hip_xxh32(_ptr(a), a.size)
+    out = ctypes.c_uint32()
+    rc = _lib.load().lz4hip_xxh32_checked(_ptr(a), a.size, ctypes.addressof(out))
+    if rc < 0:  # never a silent 0: a failed call is an error, not a checksum
+        raise _lib.Lz4HipError(int(rc), _lib.last_error())
+    return out.value
 
 
 class Compressor:

@@ -1,0 +1,233 @@
+// abi_common.h -- host-side helpers shared by the files that implement the C ABI
+// (abi.hip: device entry points and small host helpers; host_api.hip: host-pointer entry
+// points and the lz4hip_stream handle).  Host code only.
+#pragma once
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+
+namespace lz4hip {
+
+extern thread_local std::string g_err;  // text behind lz4hip_last_error()
+
+inline int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+inline int hip_fail(hipError_t e, const char *what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return LZ4HIP_ERR_HIP;
+}
+#define HIPCHK(call)                                      \
+    do {                                                  \
+        hipError_t e_ = (call);                           \
+        if (e_ != hipSuccess) return hip_fail(e_, #call); \
+    } while (0)
+
+inline bool valid_block_size(uint32_t bs) {
+    return bs == LZ4HIP_BLOCK_64KB || bs == LZ4HIP_BLOCK_256KB || bs == LZ4HIP_BLOCK_1MB ||
+           bs == LZ4HIP_BLOCK_4MB;
+}
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+constexpr size_t kFastSlots = 8192;             // resident waves of the global-table Fast kernel
+constexpr size_t kFastSlotBytes = 65536 * 2;    // one u16 table
+constexpr size_t kFastCounterBytes = 256;       // tail of the Fast workspace: the block counter of the dynamic schedule
+constexpr size_t kFastGlobalMinBlocks = 257;    // up to one block per CU the LDS-table kernel is used
+constexpr size_t kHcSlots = 4096;               // resident workgroups of the HC kernel
+constexpr uint32_t kLegacyBlock = 8u << 20;     // blocks.go:11, frame.go:49
+constexpr size_t kMaxSingleBlock = 1u << 30;    // int32 positions inside a block
+
+// A Fast workspace is `slots` hash tables followed, when the caller sized it with
+// lz4hip_fast_workspace_bytes, by the block counter of the dynamic schedule.  A workspace
+// without room for the counter still works: blocks are then dealt round-robin.
+inline uint32_t *fast_ws_split(void *ws, size_t bytes, size_t &slots) {
+    slots = ws ? bytes / kFastSlotBytes : 0;
+    if (slots > kFastSlots) slots = kFastSlots;
+    if (!slots || bytes - slots * kFastSlotBytes < sizeof(uint32_t)) return nullptr;
+    return reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(ws) + slots * kFastSlotBytes);
+}
+
+// The host-pointer entry points run on the calling thread's own stream
+// (hipStreamPerThread), never on the legacy null stream: calls made from several OS
+// threads (cgo runs each goroutine's call on its own thread) then overlap on the GPU
+// instead of queueing behind each other.  hcopy = a blocking copy on that stream.
+const hipStream_t kHostStream = hipStreamPerThread;
+inline hipError_t hcopy(void *dst, const void *src, size_t n, hipMemcpyKind kind) {
+    hipError_t e = hipMemcpyAsync(dst, src, n, kind, kHostStream);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(kHostStream);
+}
+
+// RAII device buffer for the host-pointer entry points: stream-ordered allocation on the
+// calling thread's stream.  hipMalloc/hipFree would do, but hipFree waits for EVERY stream
+// of the device, which serialises concurrent callers behind each other's kernels.
+// Every use of the buffer on another stream is synchronised before the owner returns.
+// After lz4hip_init() freed memory stays in the device's pool, so a call's buffers cost
+// no driver allocation (the reference keeps its buffers in sync.Pools the same way).
+struct DevBuf {
+    void *p = nullptr;
+    hipError_t alloc(size_t n) { return hipMallocAsync(&p, n ? n : 16, kHostStream); }
+    ~DevBuf() {
+        if (p) (void)hipFreeAsync(p, kHostStream);
+    }
+    template <class T> T *as() { return static_cast<T *>(p); }
+};
+
+// A second, non-blocking stream owned by one call.  The destructor waits for it, so
+// buffers declared BEFORE it outlive everything queued on it -- on every exit path.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipError_t create() { return hipStreamCreateWithFlags(&s, hipStreamNonBlocking); }
+    ~SideStream() {
+        if (s) {
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamDestroy(s);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------
+// XXHZero on the host: internal/xxh32/xxh32zero.go:22-139 restated, Sum32's
+// `uint32(totalLen) >= 16` included (:113-118, SURVEY trap T6).  Product code: the
+// host-pointer frame entry points and the lz4hip_stream handle compute the CONTENT
+// checksum here -- the bytes are in host memory on those paths anyway, and one host core
+// runs this serial chain four times faster than a GPU lane chain does.
+// ---------------------------------------------------------------------------------
+struct HostXXH {
+    uint32_t v[4];
+    uint64_t total;
+    uint8_t buf[16];
+    int used;
+
+    static uint32_t rol(uint32_t u, int k) { return (u << k) | (u >> (32 - k)); }
+    static uint32_t rd(const uint8_t *p) {
+        uint32_t w;
+        memcpy(&w, p, 4);
+        return w;
+    }
+    HostXXH() { reset(); }
+    void reset() {  // :37-44
+        v[0] = 606290984u;
+        v[1] = 2246822519u;
+        v[2] = 0u;
+        v[3] = 1640531535u;
+        total = 0;
+        used = 0;
+    }
+    static void stripes(uint32_t *v, const uint8_t *p, size_t n16) {  // updateGo, :90-109
+        uint32_t a = v[0], b = v[1], c = v[2], d = v[3];
+        for (size_t i = 0; i < n16; i++, p += 16) {
+            a = rol(a + rd(p) * 2246822519u, 13) * 2654435761u;
+            b = rol(b + rd(p + 4) * 2246822519u, 13) * 2654435761u;
+            c = rol(c + rd(p + 8) * 2246822519u, 13) * 2654435761u;
+            d = rol(d + rd(p + 12) * 2246822519u, 13) * 2654435761u;
+        }
+        v[0] = a, v[1] = b, v[2] = c, v[3] = d;
+    }
+    void write(const uint8_t *in, size_t n) {  // :58-86
+        if (total == 0) reset();
+        total += n;
+        const size_t room = 16 - (size_t)used;
+        if (n < room) {
+            if (n) memcpy(buf + used, in, n);
+            used += (int)n;
+            return;
+        }
+        if (used) {
+            memcpy(buf + used, in, room);
+            stripes(v, buf, 1);
+            in += room;
+            n -= room;
+        }
+        stripes(v, in, n / 16);
+        used = (int)(n % 16);
+        if (used) memcpy(buf, in + n - used, (size_t)used);
+    }
+    uint32_t sum32() const {  // :112-139
+        uint32_t h = (uint32_t)total;
+        if (h >= 16)
+            h += rol(v[0], 1) + rol(v[1], 7) + rol(v[2], 12) + rol(v[3], 18);
+        else
+            h += 374761393u;
+        int p = 0;
+        for (; p + 4 <= used; p += 4) h = rol(h + rd(buf + p) * 3266489917u, 17) * 668265263u;
+        for (; p < used; p++) h = rol(h + buf[p] * 374761393u, 11) * 2654435761u;
+        h ^= h >> 15;
+        h *= 2246822519u;
+        h ^= h >> 13;
+        h *= 3266489917u;
+        h ^= h >> 16;
+        return h;
+    }
+};
+
+// The content checksum of one call, on a helper thread that follows the producer's
+// progress mark: lz4stream/block.go:257-259 (Write folds every block's src in stream
+// order) and :336-338 / :174-176 (the reader's collector does the same with decoded
+// blocks).  The producer publishes "bytes [0, upto) of base are final"; finish() waits
+// for the hash of everything published.  The state it updates outlives the call
+// (lz4hip_stream) or is local to it (frame entry points).
+class HashFollower {
+public:
+    HashFollower(HostXXH *st, const uint8_t *base) : st_(st), base_(base) {
+        th_ = std::thread([this] { run(); });
+    }
+    ~HashFollower() { finish(); }
+    void publish(size_t upto) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            avail_ = upto;
+        }
+        cv_.notify_one();
+    }
+    void finish() {
+        if (!th_.joinable()) return;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            done_ = true;
+        }
+        cv_.notify_one();
+        th_.join();
+    }
+
+private:
+    void run() {
+        size_t at = 0;
+        for (;;) {
+            size_t upto;
+            bool done;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return avail_ > at || done_; });
+                upto = avail_;
+                done = done_;
+            }
+            if (upto > at) {
+                st_->write(base_ + at, upto - at);
+                at = upto;
+            } else if (done) {
+                return;
+            }
+        }
+    }
+    HostXXH *st_;
+    const uint8_t *base_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    size_t avail_ = 0;
+    bool done_ = false;
+    std::thread th_;
+};
+
+}  // namespace lz4hip

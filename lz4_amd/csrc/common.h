@@ -101,9 +101,12 @@ hipError_t launch_hc(const uint8_t *src, size_t n, uint32_t bs, size_t nb, uint3
                      int dst_mode,
                      uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result, uint32_t *ws,
                      size_t slots, uint32_t *next_block, hipStream_t st);
-hipError_t launch_decode(const uint8_t *src, const uint64_t *off, const uint32_t *sw, size_t nb,
-                         uint8_t *dst, size_t dst_stride, uint32_t dst_len, uint32_t prefix,
-                         int32_t *out_len, hipStream_t st);
+// src_len: bytes readable at src (a block whose span leaves them yields -1 unread).
+// History of every block: `prefix` bytes ending at dict_end, or, with dict_end == nullptr,
+// the `prefix` bytes in memory right in front of the block's dst.
+hipError_t launch_decode(const uint8_t *src, size_t src_len, const uint64_t *off, const uint32_t *sw,
+                         size_t nb, uint8_t *dst, size_t dst_stride, uint32_t dst_len,
+                         uint32_t prefix, const uint8_t *dict_end, int32_t *out_len, hipStream_t st);
 hipError_t launch_decode_linked(const uint8_t *src, const uint64_t *off, const uint32_t *sw,
                                 size_t nb, uint8_t *dst, uint32_t block_cap, size_t dst_cap,
                                 int32_t *out_len, uint64_t *out_off, hipStream_t st);

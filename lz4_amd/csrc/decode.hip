@@ -1,14 +1,12 @@
-// decode4.hip -- window-parallel LZ4 block decoder, generation 4: decode3 with a
-// 256-byte window and compacted token lanes.
+// decode.hip -- window-parallel two-pass LZ4 block decoder.
 //
 // Same results as decodeBlock (internal/lz4block/decode_other.go:10-137,
 // decode_amd64.s:24-448) / UncompressBlock (block.go:44-52).
 //
-// decode3 parses 64 compressed bytes per window; on text that is ~9 sequences, so
-// pass 2 (the copies, with their divergent tails) runs with 9 of 64 lanes active and
-// every per-window cost (offset scan, bounds ballots, stage hand-offs, flush) is paid
-// per ~105 output bytes.  PMC put it at 1.77 scalar + 0.54 branch + 1.88 vector
-// instructions per output byte: instruction issue, not memory, bounds it.  Here
+// A 64-byte window holds ~9 sequences on text, so a pass 2 over it (the copies, with
+// their divergent tails) would run with 9 of 64 lanes active and every per-window cost
+// (offset scan, bounds ballots, stage hand-offs, flush) would be paid per ~105 output
+// bytes: instruction issue, not memory, bounds this kernel.  So
 //   * pass 1 parses kSets candidate headers per lane (256 compressed bytes),
 //   * the linked tokens are compacted through LDS into lanes 0..ntok-1 in stream
 //     order (a sequence takes at least 3 bytes: three sets hold at most 64 tokens, and
@@ -80,10 +78,14 @@ __device__ __forceinline__ Hdr parse_header(const uint8_t *ib, const int pos, co
 
 // `stage`: kStage bytes of LDS owned by this wave, 16-byte aligned; `ibuf`: kIn bytes
 // of LDS holding in[ibase, iend) (one coalesced refill per ~8 windows); `desc`: 64
-// token descriptors.
-__device__ int decode4_block(const uint8_t *__restrict__ in, const int n, uint8_t *d, const int dlen,
-                             const int prefix, const int lane, uint8_t *stage, uint8_t *ibuf,
-                             uint2 *desc) {
+// token descriptors.  History before d: `prefix` bytes ending at `hist_end`.  hist_end
+// == d means the history sits in memory right in front of d (single-block call, linked
+// frames); otherwise it is a separate dictionary (decode_other.go:109-121), and a match
+// that starts before d goes through the serial sequence decoder, which reads both parts.
+__device__ int decode_block(const uint8_t *__restrict__ in, const int n, uint8_t *d, const int dlen,
+                             const int prefix, const uint8_t *hist_end, const int lane,
+                             uint8_t *stage, uint8_t *ibuf, uint2 *desc) {
+    const bool split = hist_end != d;
     int si = 0, di = 0, ibase = 0, iend = 0;
     for (;;) {
         si = (int)rfl((uint32_t)si);
@@ -120,7 +122,7 @@ __device__ int decode4_block(const uint8_t *__restrict__ in, const int n, uint8_
             pk1[0] = (uint32_t)h.ml | ((uint32_t)(h.lpos - si) << 9) | ((uint32_t)(h.end - si) << 18);
         }
         if (!(G[0] & 1)) {  // the sequence at si itself is not a plain one
-            const int st = d2_serial_sequence(in, n, d, dlen, prefix, si, di, lane);
+            const int st = d2_serial_sequence(in, n, d, dlen, prefix, hist_end, si, di, lane);
             if (st < 0) return -1;
             if (st > 0) return di;
             continue;
@@ -208,11 +210,13 @@ __device__ int decode4_block(const uint8_t *__restrict__ in, const int n, uint8_
         const int myout = incl - outlen;  // offset of my literals from di
         const int mstart = myout + lit;   // offset of my match from di
         // the reference's bounds: literals and match fit dst, offset inside history
-        const bool bad = lane < ntok && (di + mstart + ml > dlen || off > di + mstart + prefix);
+        // (with a separate dictionary, also a match that starts inside it: serial path)
+        const bool bad = lane < ntok && (di + mstart + ml > dlen ||
+                                         off > di + mstart + (split ? 0 : prefix));
         const uint64_t B = ballot(bad);
         if (B) ntok = __builtin_ctzll(B);  // stop before the first violation
         if (ntok == 0) {
-            const int st = d2_serial_sequence(in, n, d, dlen, prefix, si, di, lane);
+            const int st = d2_serial_sequence(in, n, d, dlen, prefix, hist_end, si, di, lane);
             if (st < 0) return -1;
             if (st > 0) return di;
             continue;
@@ -300,13 +304,13 @@ __device__ int decode4_block(const uint8_t *__restrict__ in, const int n, uint8_
 
 }  // namespace
 
-#ifndef LZ4HIP_D4_WAVES
-#define LZ4HIP_D4_WAVES 8
+#ifndef LZ4HIP_DECODE_WAVES
+#define LZ4HIP_DECODE_WAVES 8
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LZ4HIP_D4_WAVES, 8))) void k_decode4(
-    const uint8_t *__restrict__ src, const uint64_t *__restrict__ off, const uint32_t *__restrict__ sw,
-    size_t nb, uint8_t *dst, size_t dst_stride, uint32_t dst_len, uint32_t prefix,
-    int32_t *__restrict__ out_len) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LZ4HIP_DECODE_WAVES, 8))) void k_decode(
+    const uint8_t *__restrict__ src, size_t src_len, const uint64_t *__restrict__ off,
+    const uint32_t *__restrict__ sw, size_t nb, uint8_t *dst, size_t dst_stride, uint32_t dst_len,
+    uint32_t prefix, const uint8_t *__restrict__ dict_end, int32_t *__restrict__ out_len) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kStage + 16];
     __shared__ __attribute__((aligned(16))) uint8_t ibuf[kIn + 16];
     __shared__ uint2 desc[kWave];
@@ -315,16 +319,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LZ4HIP_D4_WA
     if (b >= nb) return;
     const uint32_t w = sw[b];
     const int n = (int)(w & 0x7FFFFFFFu);
-    const uint8_t *in = src + off[b];
+    const uint64_t o = off[b];
+    const uint8_t *in = src + o;
     uint8_t *d = dst + b * dst_stride;
     int r;
-    if (w >> 31) {  // stored raw: n := copy(dst, b.data), lz4stream/block.go:320-322
+    if (o > src_len || (uint64_t)n > src_len - o) {
+        r = -1;  // the block's span leaves the source buffer: nothing of it is read
+    } else if (w >> 31) {  // stored raw: n := copy(dst, b.data), lz4stream/block.go:320-322
         r = (uint32_t)n > dst_len ? (int)dst_len : n;
         wave_copy16(d, in, r, lane);
     } else if (n == 0) {
         r = 0;  // block.go:45-47
     } else {
-        r = decode4_block(in, n, d, (int)dst_len, (int)prefix, lane, stage, ibuf, desc);
+        // dict_end: a dictionary shared by every block of the batch; NULL: the `prefix`
+        // bytes in front of d are the history
+        r = decode_block(in, n, d, (int)dst_len, (int)prefix, dict_end ? dict_end : d, lane, stage,
+                         ibuf, desc);
     }
     if (lane == 0) out_len[b] = r;
 }
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LZ4HIP_D4_WA
 // < 64 KiB, so `offset > di + len(dict)` fires exactly when `offset > di + prefix`.
 // out_off[b] = start of block b's output, out_len[b] = its length or -1; the walk
 // stops at the first bad block (later blocks report -1).
-__global__ __launch_bounds__(64) void k_decode4_linked(const uint8_t *__restrict__ src,
+__global__ __launch_bounds__(64) void k_decode_linked(const uint8_t *__restrict__ src,
                                                        const uint64_t *__restrict__ off,
                                                        const uint32_t *__restrict__ sw, size_t nb,
                                                        uint8_t *dst, uint32_t block_cap,
@@ -368,7 +378,7 @@ __global__ __launch_bounds__(64) void k_decode4_linked(const uint8_t *__restrict
                 r = 0;
             } else {
                 const int prefix = total > (size_t)kWinSize ? kWinSize : (int)total;
-                r = decode4_block(in, n, d, (int)cap, prefix, lane, stage, ibuf, desc);
+                r = decode_block(in, n, d, (int)cap, prefix, d, lane, stage, ibuf, desc);
             }
             r = (int)rfl((uint32_t)r);
             // this wave's stores must be visible to its own later loads
@@ -387,17 +397,17 @@ hipError_t launch_decode_linked(const uint8_t *src, const uint64_t *off, const u
                                 size_t nb, uint8_t *dst, uint32_t block_cap, size_t dst_cap,
                                 int32_t *out_len, uint64_t *out_off, hipStream_t st) {
     if (nb == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_decode4_linked, dim3(1), dim3(kWave), 0, st, src, off, sw, nb, dst,
+    hipLaunchKernelGGL(k_decode_linked, dim3(1), dim3(kWave), 0, st, src, off, sw, nb, dst,
                        block_cap, dst_cap, out_len, out_off);
     return hipGetLastError();
 }
 
-hipError_t launch_decode(const uint8_t *src, const uint64_t *off, const uint32_t *sw, size_t nb,
-                          uint8_t *dst, size_t dst_stride, uint32_t dst_len, uint32_t prefix,
-                          int32_t *out_len, hipStream_t st) {
+hipError_t launch_decode(const uint8_t *src, size_t src_len, const uint64_t *off, const uint32_t *sw,
+                         size_t nb, uint8_t *dst, size_t dst_stride, uint32_t dst_len,
+                         uint32_t prefix, const uint8_t *dict_end, int32_t *out_len, hipStream_t st) {
     if (nb == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_decode4, dim3((unsigned)nb), dim3(kWave), 0, st, src, off, sw, nb, dst,
-                       dst_stride, dst_len, prefix, out_len);
+    hipLaunchKernelGGL(k_decode, dim3((unsigned)nb), dim3(kWave), 0, st, src, src_len, off, sw, nb,
+                       dst, dst_stride, dst_len, prefix, dict_end, out_len);
     return hipGetLastError();
 }
 

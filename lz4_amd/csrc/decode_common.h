@@ -1,4 +1,4 @@
-// decode_common.h -- helpers shared by the window-parallel decoders (decode3/decode4).
+// decode_common.h -- helpers of the window-parallel decoder (decode.hip).
 #pragma once
 #include "common.h"
 
@@ -40,10 +40,11 @@ __device__ __forceinline__ bool d2_len_ext(const uint8_t *in, int n, int &p, int
 }
 
 // One sequence, wave-uniform, every check of the reference in its order.
-// Returns 0 = continue, 1 = block finished, -1 = error.
+// Returns 0 = continue, 1 = block finished, -1 = error.  `prefix` bytes of history end
+// at hist_end (== d: they sit right in front of d; else a separate dictionary).
 __device__ __forceinline__ int d2_serial_sequence(const uint8_t *__restrict__ in, int n, uint8_t *d,
-                                                  int dlen, int prefix, int &si, int &di,
-                                                  int lane) {
+                                                  int dlen, int prefix, const uint8_t *hist_end,
+                                                  int &si, int &di, int lane) {
     const uint32_t tok = in[si++];
     int l_len = (int)(tok >> 4);
     if (l_len > 0) {
@@ -63,11 +64,21 @@ __device__ __forceinline__ int d2_serial_sequence(const uint8_t *__restrict__ in
     if (m_len == kMinMatch + 0xF && !d2_len_ext(in, n, si, m_len, lane)) return -1;
     if (m_len > dlen - di) return -1;
     if (offset > di + prefix) return -1;  // before the dictionary start: :109-113
-    const uint8_t *from = d + di - offset;
-    if (m_len <= offset) {
-        wave_copy(d + di, from, m_len, lane);
+    if (offset > di && hist_end != d) {
+        // decode_other.go:109-121: the first offset - di bytes come from the dictionary's
+        // tail, the rest from dst[0:]; byte k of the match is byte k % offset of that source
+        const int q0 = di - offset;  // < 0: position of the match source relative to d
+        for (int k = lane; k < m_len; k += kWave) {
+            const int q = q0 + (m_len <= offset ? k : k % offset);
+            d[di + k] = q < 0 ? hist_end[q] : d[q];
+        }
     } else {
-        for (int k = lane; k < m_len; k += kWave) d[di + k] = from[k % offset];
+        const uint8_t *from = d + di - offset;
+        if (m_len <= offset) {
+            wave_copy(d + di, from, m_len, lane);
+        } else {
+            for (int k = lane; k < m_len; k += kWave) d[di + k] = from[k % offset];
+        }
     }
     di += m_len;
     return si < n ? 0 : 1;  // a block may end right after a match (decode_other.go:28)

@@ -97,7 +97,7 @@ __device__ __forceinline__ int len_tail_size(int len) {  // bytes after the toke
 }
 
 template <bool kGlobal, typename TablePtr>
-__device__ __forceinline__ int fast3_block(const uint8_t *__restrict__ s, const int n,
+__device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const int n,
                                            uint8_t *__restrict__ d, const int dlen,
                                            TablePtr table, uint32_t *tag, uint8_t *sbuf,
                                            uint8_t *obuf, uint32_t *inuse, const int lane) {
@@ -455,7 +455,7 @@ __device__ __forceinline__ int fast3_block(const uint8_t *__restrict__ s, const 
 }
 
 // Table in LDS: one wave (= one workgroup) per block, one block per CU.
-__global__ __launch_bounds__(64) void k_fast3_lds(const uint8_t *__restrict__ src, size_t n_total,
+__global__ __launch_bounds__(64) void k_fast_lds(const uint8_t *__restrict__ src, size_t n_total,
                                                   uint32_t block_size, int dst_mode,
                                                   uint32_t dst_len_x, uint8_t *__restrict__ dst,
                                                   size_t dst_stride,
@@ -469,14 +469,14 @@ __global__ __launch_bounds__(64) void k_fast3_lds(const uint8_t *__restrict__ sr
     const size_t start = b * (size_t)block_size;
     const size_t left = n_total > start ? n_total - start : 0;
     const int n = (int)(left < block_size ? left : block_size);
-    const int r = fast3_block<false>(src + start, n, dst + b * dst_stride,
+    const int r = fast_block<false>(src + start, n, dst + b * dst_stride,
                                      block_dlen2(dst_mode, n, dst_len_x), table, tag, sbuf, obuf,
                                      nullptr, lane);
     if (lane == 0) result[b] = r;
 }
 
 // Table in a global-memory slot per resident wave; many waves per CU.
-__global__ __launch_bounds__(64) void k_fast3_gtab(const uint8_t *__restrict__ src, size_t n_total,
+__global__ __launch_bounds__(64) void k_fast_gtab(const uint8_t *__restrict__ src, size_t n_total,
                                                    uint32_t block_size, size_t nb, int dst_mode,
                                                    uint32_t dst_len_x, uint8_t *__restrict__ dst,
                                                    size_t dst_stride,
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(64) void k_fast3_gtab(const uint8_t *__restrict__ s
         const size_t start = b * (size_t)block_size;
         const size_t left = n_total > start ? n_total - start : 0;
         const int n = (int)(left < block_size ? left : block_size);
-        const int r = fast3_block<true>(src + start, n, dst + b * dst_stride,
+        const int r = fast_block<true>(src + start, n, dst + b * dst_stride,
                                                    block_dlen2(dst_mode, n, dst_len_x), table, tag,
                                                    sbuf, obuf, inuse, lane);
         if (lane == 0) result[b] = r;
@@ -528,10 +528,10 @@ hipError_t launch_fast(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int
             const hipError_t e = hipMemsetAsync(next_block, 0, sizeof(uint32_t), st);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(k_fast3_gtab, dim3((unsigned)grid), dim3(kWave), 0, st, src, n, bs, nb,
+        hipLaunchKernelGGL(k_fast_gtab, dim3((unsigned)grid), dim3(kWave), 0, st, src, n, bs, nb,
                            dst_mode, dst_len_x, dst, dst_stride, result, ws, next_block);
     } else {
-        hipLaunchKernelGGL(k_fast3_lds, dim3((unsigned)nb), dim3(kWave), 0, st, src, n, bs,
+        hipLaunchKernelGGL(k_fast_lds, dim3((unsigned)nb), dim3(kWave), 0, st, src, n, bs,
                            dst_mode, dst_len_x, dst, dst_stride, result);
     }
     return hipGetLastError();

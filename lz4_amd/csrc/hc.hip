@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
     if (depth == 0) depth = kWinSize;  // block.go:343-345
 
     // resident waves take their next block from a counter when they finish one (as
-    // k_fast3_gtab does; the reference's goroutines, writer.go:130-142); without a counter
+    // k_fast_gtab does; the reference's goroutines, writer.go:130-142); without a counter
     // the blocks are dealt round-robin
     auto take = [&]() -> size_t {
         uint32_t t = 0;

@@ -75,12 +75,15 @@ def compress_blocks(src, block_size, level=0, dst_mode=_lib.DST_FRAME, out=None,
     return out[:nb], result[:nb]
 
 
-def uncompress_blocks(src, src_off, size_words, dst_len, out=None, out_len=None, dst_stride=None):
+def uncompress_blocks(src, src_off, size_words, dst_len, out=None, out_len=None, dst_stride=None,
+                      dict=None):
     """Decode n independent blocks (block.go:44-52 per block).
 
     src: CUDA uint8 holding the payloads; src_off int64/uint64 [nb] byte offsets;
-    size_words int32/uint32 [nb] (bit 31 = stored raw).  Returns (out [nb, stride],
-    out_len [nb] int32; -1 = ErrInvalidSourceShortBuffer).
+    size_words int32/uint32 [nb] (bit 31 = stored raw).  dict: optional CUDA uint8
+    dictionary shared by every block (lz4.UncompressBlockWithDict, lz4.go:47-49).
+    Returns (out [nb, stride], out_len [nb] int32; -1 = ErrInvalidSourceShortBuffer;
+    a block whose span leaves `src` is rejected without being read).
     """
     _u8(src)
     lib = _lib.load()
@@ -90,9 +93,13 @@ def uncompress_blocks(src, src_off, size_words, dst_len, out=None, out_len=None,
         out = torch.empty((max(nb, 1), stride), dtype=torch.uint8, device=src.device)
     if out_len is None:
         out_len = torch.empty(max(nb, 1), dtype=torch.int32, device=src.device)
-    _lib.check(lib.lz4hip_uncompress_blocks(src.data_ptr(), src_off.data_ptr(),
+    if dict is not None:
+        _u8(dict)
+    _lib.check(lib.lz4hip_uncompress_blocks(src.data_ptr(), src.numel(), src_off.data_ptr(),
                                             size_words.data_ptr(), nb, out.data_ptr(), stride,
-                                            dst_len, out_len.data_ptr(), _stream_ptr()))
+                                            dst_len, dict.data_ptr() if dict is not None else None,
+                                            dict.numel() if dict is not None else 0,
+                                            out_len.data_ptr(), _stream_ptr()))
     return out[:nb], out_len[:nb]
 
 

@@ -630,7 +630,7 @@ static int64_t legacy_uncompress(const uint8_t *src, size_t n, size_t si, uint8_
         uint32_t x = ld32(src + si);
         si += 4;
         if (x == FRAME_MAGIC_LEGACY) continue;
-        if (x == (uint32_t)di) break; /* :289-293 */
+        if (x == (uint32_t)di) return (int64_t)di; /* :289-293: io.EOF, whatever follows */
         uint32_t size = x & 0x7FFFFFFFu;
         if (size > cap) return LZ4O_FE_BLOCK_SIZE;
         if (n - si < size) return LZ4O_FE_TRUNCATED;
@@ -647,6 +647,9 @@ static int64_t legacy_uncompress(const uint8_t *src, size_t n, size_t si, uint8_
         si += size;
         di += (size_t)got;
     }
+    /* readUint32 is an io.ReadFull of 4 bytes (lz4stream/block.go:342-345): none left is
+     * io.EOF, the clean end; one to three left is io.ErrUnexpectedEOF, an error */
+    if (n - si != 0) return LZ4O_FE_TRUNCATED;
     return (int64_t)di;
 }
 

@@ -69,9 +69,29 @@ def test_argument_validation_without_gpu():
     assert b"block size" in lib.lz4hip_last_error()
     assert lib.lz4hip_compress_fast_blocks(17, 100, 1 << 16, 0, 16, 65536, 16, None, 0, None) == _lib.ERR_ARG
     assert lib.lz4hip_compress_fast_blocks(16, 100, 1 << 16, 0, 16, 1024, 16, None, 0, None) == _lib.ERR_ARG
-    assert lib.lz4hip_uncompress_blocks(None, None, None, 4, None, 0, 0, None, None) == _lib.ERR_ARG
+    assert lib.lz4hip_uncompress_blocks(None, 0, None, None, 4, None, 0, 0, None, 0, None, None) == _lib.ERR_ARG
     # heads + 16 u16 links per entry, + 256 bytes for the block counter of the schedule
     assert lib.lz4hip_hc_workspace_bytes(1) == 65536 * 4 + 65536 * 16 * 2 + 256
+
+
+def test_bad_arguments_are_not_the_codec_verdict():
+    """-1 from the single-block calls means ErrInvalidSourceShortBuffer, which the frame
+    step turns into "store raw" (lz4stream/block.go:238-245): a call that fails for another
+    reason must return a different code (checked before any HIP call: runs without a GPU)."""
+    import ctypes as C
+    from lz4_amd import _lib
+    lib = _lib.load()
+    dst = np.zeros(64, dtype=np.uint8)
+    assert _lib.ERR_BADARG not in (-1, 0) and _lib.ERR_HIP not in (-1, 0)
+    assert lib.lz4hip_compress_block(None, 10, dst.ctypes.data, 64) == _lib.ERR_BADARG
+    assert lib.lz4hip_compress_block_hc(None, 10, dst.ctypes.data, 64, 16) == _lib.ERR_BADARG
+    assert lib.lz4hip_compress_block(dst.ctypes.data, (1 << 30) + 1, dst.ctypes.data, 64) == _lib.ERR_BADARG
+    assert lib.lz4hip_uncompress_block(None, 10, dst.ctypes.data, 64, None, 0) == _lib.ERR_BADARG
+    out = C.c_uint32(77)
+    assert lib.lz4hip_xxh32_checked(None, 10, C.addressof(out)) == _lib.ERR_BADARG and out.value == 77
+    assert lib.lz4hip_stream_create(12345, 0, 0, 4) is None and b"block size" in lib.lz4hip_last_error()
+    assert lib.lz4hip_stream_create(1 << 16, 0, 0, 0) is None
+    assert lib.lz4hip_stream_compress_blocks(None, None, 0, None, 0, None) == _lib.ERR_ARG
 
 
 def test_no_cpu_fallback_in_product_path():

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn the PMC passes of tools/pmc_bench.sh into profiles/traffic.json (per-input-byte figures).
     python tools/traffic_json.py gpurun_out/pmc_bench_TAG SIZE_GIB > profiles/traffic.json
-The timed Fast launch is the LAST k_fast3_gtab dispatch (the first one builds the decode input)."""
+The timed Fast launch is the LAST k_fast_gtab dispatch (the first one builds the decode input)."""
 import collections, csv, glob, json, sys
 d, gib = sys.argv[1], float(sys.argv[2])
 n = int(gib * 2**30)
@@ -31,7 +31,7 @@ out = {"method": "rocprofv3 --pmc, one run per counter group (TCC_EA0_RDREQ/_32B
                  "FETCH_SIZE + WRITE_SIZE as reported (the x2 FETCH_SIZE correction of MI355X_MICROARCH.md is for wide "
                  "streaming reads; these are random 2-byte gathers)" % gib,
        "input_bytes_per_launch_measured": n}
-for k in ("k_fast3_gtab", "k_decode4", "k_decode3", "k_xxh32_blocks"):
+for k in ("k_fast_gtab", "k_decode", "k_decode3", "k_xxh32_blocks"):
     if k in vals:
         out[k] = per_byte(vals[k])
 print(json.dumps(out, indent=1))
