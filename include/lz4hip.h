@@ -112,6 +112,20 @@ int lz4hip_compress_fast_blocks(const void *d_src, size_t n, uint32_t block_size
                                 void *d_dst, size_t dst_stride, int32_t *d_result,
                                 void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* The same compressor for callers that cannot allocate device memory -- code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  It has NO counterpart in
+ * the reference.  It takes no workspace: the hash tables and the block counter live in a
+ * file-scope device array of the library (64 MiB + 256 B per GPU, held until the process
+ * ends), and the call itself allocates and frees nothing.  Same arguments, kernels and
+ * output bytes as lz4hip_compress_fast_blocks.  n is limited to LZ4HIP_NOALLOC_MAX_BYTES; a
+ * larger n is rejected with LZ4HIP_ERR_ARG before anything is launched.  Every call on a GPU
+ * shares that GPU's array: calls that overlap on one GPU (different streams or threads)
+ * race on it and must be serialised by the caller. */
+#define LZ4HIP_NOALLOC_MAX_BYTES (4ull << 30)
+int lz4hip_compress_fast_blocks_noalloc(const void *d_src, size_t n, uint32_t block_size,
+                                        int dst_mode, void *d_dst, size_t dst_stride,
+                                        int32_t *d_result, void *stream);
+
 /* HC level: (*CompressorHC).CompressBlock, internal/lz4block/block.go:319-481,
  * lz4stream/block.go:235-237.  depth = chain depth (0 => 65536); the frame path
  * passes the CompressionLevel constant (options.go:154-165).

@@ -27,6 +27,7 @@ SYMBOLS = {
     "lz4hip_compress_bound": (_sz, [_sz]),
     "lz4hip_fast_workspace_bytes": (_sz, [_sz]),
     "lz4hip_compress_fast_blocks": (_int, [_vp, _sz, _u32, _int, _vp, _sz, _vp, _vp, _sz, _vp]),
+    "lz4hip_compress_fast_blocks_noalloc": (_int, [_vp, _sz, _u32, _int, _vp, _sz, _vp, _vp]),
     "lz4hip_hc_workspace_bytes": (_sz, [_sz]),
     "lz4hip_compress_hc_blocks": (_int, [_vp, _sz, _u32, _u32, _int, _vp, _sz, _vp, _vp, _sz, _vp]),
     "lz4hip_uncompress_blocks": (_int, [_vp, _sz, _vp, _vp, _sz, _vp, _sz, _u32, _vp, _sz, _vp, _vp]),

@@ -42,6 +42,39 @@ uint32_t host_xxh32_short(const uint8_t *p, size_t n) {  // n < 16
     return h;
 }
 
+// ---------------------------------------------------------------------------------
+// Scratch of lz4hip_compress_fast_blocks_noalloc: the Fast kernel's workspace (hash tables
+// of the resident waves + the block counter of the dynamic schedule) as a file-scope device
+// array instead of a caller's allocation.  Every GPU the library runs on holds its own copy
+// (64 MiB + 256 B) at its own address until the process ends.  `scratch` is only a
+// host-side stand-in for the symbol: the memory is reached through the per-device address
+// that hipGetSymbolAddress returns, never through the name.
+// ---------------------------------------------------------------------------------
+constexpr size_t kNoAllocSlots = 512;  // two resident waves per CU
+constexpr size_t kNoAllocBytes = kNoAllocSlots * kFastSlotBytes + kFastCounterBytes;
+constexpr size_t kNoAllocMaxInput = 4ull << 30;  // LZ4HIP_NOALLOC_MAX_BYTES
+static_assert(kNoAllocMaxInput == LZ4HIP_NOALLOC_MAX_BYTES, "header and library disagree");
+static __device__ __align__(256) uint8_t scratch[kNoAllocBytes];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void *g_scratch_ptr[kMaxDevices];  // per device; nullptr = not resolved yet
+
+// Address of the CURRENT device's copy of `scratch` (resolved once per device).
+int scratch_address(void **out) {
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(LZ4HIP_ERR_ARG, "device index out of range");
+    std::lock_guard<std::mutex> g(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return LZ4HIP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -69,7 +102,18 @@ int lz4hip_init(int device) {
         uint64_t keep = UINT64_MAX;
         HIPCHK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
     }
-    return LZ4HIP_OK;
+    // the scratch of the entry point that allocates nothing, resolved per device with that
+    // device current (lz4hip_compress_fast_blocks_noalloc resolves it itself otherwise)
+    int prev = 0;
+    HIPCHK(hipGetDevice(&prev));
+    int rc = LZ4HIP_OK;
+    for (int d = device < 0 ? 0 : device; d < (device < 0 ? n : device + 1) && rc == LZ4HIP_OK; d++) {
+        void *p = nullptr;
+        hipError_t e = hipSetDevice(d);
+        rc = e == hipSuccess ? scratch_address(&p) : hip_fail(e, "hipSetDevice");
+    }
+    (void)hipSetDevice(prev);
+    return rc;
 }
 
 int lz4hip_shutdown(void) {
@@ -118,6 +162,22 @@ int lz4hip_compress_fast_blocks(const void *d_src, size_t n, uint32_t block_size
                        dst_stride, d_result, (uint16_t *)d_workspace, slots, next_block,
                        (hipStream_t)stream));
     return LZ4HIP_OK;
+}
+
+int lz4hip_compress_fast_blocks_noalloc(const void *d_src, size_t n, uint32_t block_size,
+                                        int dst_mode, void *d_dst, size_t dst_stride,
+                                        int32_t *d_result, void *stream) {
+    if (n > kNoAllocMaxInput)
+        return fail(LZ4HIP_ERR_ARG, "n exceeds LZ4HIP_NOALLOC_MAX_BYTES (4 GiB): split the call or use "
+                                    "lz4hip_compress_fast_blocks with a workspace");
+    void *ws = nullptr;
+    const int rc = scratch_address(&ws);
+    if (rc != LZ4HIP_OK) return rc;
+    // Same kernels and launch as the entry point with a caller's workspace; the launch
+    // re-arms the block counter in the scratch tail (hipMemsetAsync on `stream`), the tables
+    // need no clearing (the kernel's in-use bitmap lives in LDS).
+    return lz4hip_compress_fast_blocks(d_src, n, block_size, dst_mode, d_dst, dst_stride, d_result,
+                                       ws, kNoAllocBytes, stream);
 }
 
 size_t lz4hip_hc_workspace_bytes(size_t n_blocks) {
