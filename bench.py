@@ -13,6 +13,12 @@ One step = one pass of the hot path over one synthetic batch per GPU:
 value = steps * (N_a + N_b) * n_gpus / time.  Blocks shard by contiguous range,
 one process per GPU, no data-path collective ("scaling": "weak").
 
+After the timed region the same run exercises the cfg5 FRAME path through
+lz4_amd.shard (Writer: compress + span gather to rank 0 + assembly; Reader: index,
+span scatter, decode, verification), with and without the content checksum, on
+`--frame-gib` GiB per GPU of the mixed corpus in 4 MiB blocks, and reports it under
+"frame_path" (extra keys; the headline metric does not include it).
+
     python bench.py [--gpus N] [--steps K] [--warmup W] [--size-gib G]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 """
@@ -41,6 +47,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size-gib", type=float, default=8.0, help="GiB per corpus per GPU")
+    ap.add_argument("--frame-gib", type=float, default=2.0,
+                    help="GiB per GPU for the cfg5 frame path after the timed region (0: skip)")
     ap.add_argument("--cpu-sample-mib", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -58,13 +66,15 @@ def main():
     dev_index = 0 if one_dev else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_dev:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    # one process per GPU over RCCL; a single rank still gets a group of one, so that the
+    # frame path below is the same code at every N
+    if one_dev:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     def barrier():
         torch.cuda.synchronize()
@@ -194,6 +204,52 @@ def main():
                    "compress_GBps": round(m * reps / tc / 1e9, 3),
                    "decompress_GBps": round(m * reps / td / 1e9, 3)}
 
+    # ---- cfg5 frame path through lz4_amd.shard (outside the headline's timed region) ----
+    frame_path = None
+    if args.frame_gib > 0:
+        from lz4_amd import shard
+        BS_F = 1 << 22
+        share = min(int(args.frame_gib * (1 << 30)), n) // BS_F * BS_F
+        src_f = mixed[:share]               # this rank's block range of the stream
+        n_total = share * world
+        del comp, out
+        torch.cuda.empty_cache()
+        fp = {"write_GBps": {}, "read_GBps": {}, "phases_s": {}}
+        ok_rt = True
+        for label, flags in (("no_content_checksum", 1), ("content_checksum", 3)):
+            ws, rs = {}, {}
+            shard.frame_compress_sharded(src_f[:BS_F], BS_F * world, BS_F, flags, 0)   # warm-up
+            barrier()
+            t0 = time.perf_counter()
+            frame = shard.frame_compress_sharded(src_f, n_total, BS_F, flags, 0, stats=ws)
+            barrier()
+            t1 = time.perf_counter()
+            flat, _, tot = shard.frame_uncompress_sharded(frame, frame.numel() if rank == 0 else 0, stats=rs)
+            barrier()
+            t2 = time.perf_counter()
+            ok_rt &= tot == n_total and torch.equal(flat, src_f)
+            fp["write_GBps"][label] = round(n_total / (t1 - t0) / 1e9, 3)
+            fp["read_GBps"][label] = round(n_total / (t2 - t1) / 1e9, 3)
+            fp["phases_s"][label] = {"write": {k: round(v, 4) for k, v in ws.items() if k.endswith("_s")},
+                                     "read": {k: round(v, 4) for k, v in rs.items() if k.endswith("_s")}}
+            if rank == 0 and flags == 1:
+                gb = ws.get("gather_bytes", 0)
+                peak = 153.0 * min(world - 1, 7)
+                fp["gather"] = {"bytes": gb, "seconds": round(ws.get("gather_s", 0.0), 4),
+                                "GBps": round(gb / max(ws.get("gather_s", 0.0), 1e-9) / 1e9, 2) if gb else 0.0,
+                                "peak_GBps": peak,
+                                "note": "spans received straight into the frame, one xGMI link per sender "
+                                        "(7 x 153 GB/s inbound at the root)"}
+                fp["frame_bytes"] = int(frame.numel())
+            del frame, flat
+        flag = torch.tensor([1 if ok_rt else 0], dtype=torch.int64, device="cpu" if one_dev else device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        fp["round_trip_equals_source"] = bool(flag.item())
+        fp["workload"] = ("cfg5 share: %.2f GiB/GPU of the mixed corpus, 4MB blocks, xxh32 block checksums, "
+                          "Writer + Reader through lz4_amd.shard; content checksum chain on the host"
+                          % (share / 2**30))
+        frame_path = fp
+
     if rank == 0:
         total = args.steps * 2 * n * world
         alg_bytes = n + c_mixed + 8 * nb_c  # N read + C written + 8 B/block
@@ -245,11 +301,11 @@ def main():
                          "decode_frac": round((n + c_text) / t_dec / 1e9 / HBM_PEAK_GBPS, 5)},
             "cpu_baseline": cpu,
             "parity": parity,
+            "frame_path": frame_path,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

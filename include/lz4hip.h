@@ -175,6 +175,14 @@ int lz4hip_xxh32_stream(const void *d_src, size_t n, uint32_t *d_out, void *stre
 int lz4hip_xxh32_stream_update(const void *d_src, size_t n, uint32_t *d_state, int first,
                                int final_piece, uint32_t *d_digest, void *stream);
 
+/* The same chained checksum with the chain on the HOST: the bytes of d_src come down through
+ * pinned buffers and the calling thread runs XXHZero over them (synchronous; `stream`
+ * carries the copies).  h_state / h_digest are HOST memory, same layout and rules as above.
+ * One host core steps the serial chain ~4x faster than a GPU lane does, so this is the
+ * variant the sharded frame path uses for ChecksumOption(true). */
+int lz4hip_xxh32_stream_update_host(const void *d_src, size_t n, uint32_t *h_state, int first,
+                                    int final_piece, uint32_t *h_digest, void *stream);
+
 /* Frame assembly on device: FrameDescriptor.Write (frame.go:144-167),
  * FrameDataBlock.Write per block (lz4stream/block.go:254-276: size word,
  * payload or raw src when d_result[b] <= 0, checksum word unless 0) and
@@ -195,6 +203,23 @@ int lz4hip_frame_scatter(const void *d_src, size_t n, uint32_t block_size, const
                          size_t comp_stride, const int32_t *d_result,
                          const uint32_t *d_block_xxh, const uint64_t *d_entry_off,
                          size_t n_blocks, void *d_frame, uint64_t frame_base, void *stream);
+/* Reader side on device.  lz4hip_frame_index: FrameDataBlock.Read for every block of a
+ * STANDARD frame held in device memory (lz4stream/block.go:279-317), starting at the first
+ * size word (first_off = header length): payload offset, size word and -- with
+ * block_checksums -- the stored checksum of each block, up to max_blocks.  d_info (4 x
+ * int64): [0] blocks found, [1] offset behind the end mark (where the content checksum
+ * word sits) or where the walk stopped, [2] 0 or the LZ4HIP_ERR_* the reader meets there
+ * (LZ4HIP_ERR_FRAME = truncated, LZ4HIP_ERR_BLOCK_SIZE = size word above block_size),
+ * [3] 1 when max_blocks was reached before the end mark.  One lane walks the words (each
+ * one's place depends on the sizes before it).
+ * lz4hip_pack_blocks: decoded blocks sit in fixed-stride slots; block b's d_len[b] bytes
+ * (skipped when <= 0) are copied to d_flat + d_flat_off[b] -- the contiguous stream the
+ * content checksum and the caller want when blocks are not all full. */
+int lz4hip_frame_index(const void *d_frame, size_t n, uint64_t first_off, uint32_t block_size,
+                       int block_checksums, size_t max_blocks, uint64_t *d_src_off,
+                       uint32_t *d_size_words, uint32_t *d_want_xxh, int64_t *d_info, void *stream);
+int lz4hip_pack_blocks(const void *d_slots, size_t stride, const int32_t *d_len,
+                       const uint64_t *d_flat_off, size_t n_blocks, void *d_flat, void *stream);
 size_t lz4hip_frame_header(uint8_t *h_dst16, uint32_t block_size, uint32_t flags,
                            uint64_t content_size);
 size_t lz4hip_frame_trailer(uint8_t *h_dst8, uint32_t flags, uint32_t content_xxh);

@@ -288,6 +288,27 @@ int lz4hip_frame_scatter(const void *d_src, size_t n, uint32_t block_size, const
     return LZ4HIP_OK;
 }
 
+int lz4hip_frame_index(const void *d_frame, size_t n, uint64_t first_off, uint32_t block_size,
+                       int block_checksums, size_t max_blocks, uint64_t *d_src_off,
+                       uint32_t *d_size_words, uint32_t *d_want_xxh, int64_t *d_info, void *stream) {
+    if (!valid_block_size(block_size)) return fail(LZ4HIP_ERR_ARG, "invalid block size");
+    if (!d_frame || !d_src_off || !d_size_words || !d_info || (block_checksums && !d_want_xxh))
+        return fail(LZ4HIP_ERR_ARG, "null pointer");
+    HIPCHK(launch_frame_index((const uint8_t *)d_frame, n, first_off, block_size, block_checksums,
+                              max_blocks, d_src_off, d_size_words, d_want_xxh, d_info,
+                              (hipStream_t)stream));
+    return LZ4HIP_OK;
+}
+
+int lz4hip_pack_blocks(const void *d_slots, size_t stride, const int32_t *d_len,
+                       const uint64_t *d_flat_off, size_t n_blocks, void *d_flat, void *stream) {
+    if (n_blocks == 0) return LZ4HIP_OK;
+    if (!d_slots || !d_len || !d_flat_off || !d_flat) return fail(LZ4HIP_ERR_ARG, "null pointer");
+    HIPCHK(launch_pack_blocks((const uint8_t *)d_slots, stride, d_len, d_flat_off, n_blocks,
+                              (uint8_t *)d_flat, (hipStream_t)stream));
+    return LZ4HIP_OK;
+}
+
 // frame.go:144-167,202-204; frame_gen.go:7-29
 size_t lz4hip_frame_header(uint8_t *dst, uint32_t block_size, uint32_t flags,
                            uint64_t content_size) {

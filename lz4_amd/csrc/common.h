@@ -118,6 +118,9 @@ hipError_t launch_xxh32_update(const uint8_t *src, size_t n, uint32_t *state, in
 hipError_t launch_frame_layout(const int32_t *result, size_t n, uint32_t bs, size_t nb,
                                const uint32_t *xxh, uint64_t first_off, uint64_t *entry_off,
                                uint32_t *size_words, hipStream_t st);
+hipError_t launch_frame_index(const uint8_t *frame, size_t n, uint64_t first_off, uint32_t bs,
+                              int bsum, size_t max_blocks, uint64_t *off, uint32_t *sw,
+                              uint32_t *want, int64_t *info, hipStream_t st);
 hipError_t launch_pack_blocks(const uint8_t *slots, size_t stride, const int32_t *out_len,
                               const uint64_t *flat_off, size_t nb, uint8_t *flat, hipStream_t st);
 hipError_t launch_frame_scatter(const uint8_t *src, size_t n, uint32_t bs, const uint8_t *comp,

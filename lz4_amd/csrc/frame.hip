@@ -113,6 +113,68 @@ __global__ __launch_bounds__(256) void k_pack_blocks(const uint8_t *__restrict__
     if (l > 0) wg_copy(flat + flat_off[b], slots + b * stride, (size_t)l, threadIdx.x, 256);
 }
 
+// Reader side, block index of a standard frame that sits in device memory
+// (FrameDataBlock.Read per block, lz4stream/block.go:279-317): every size word's place
+// depends on the sizes before it, so one lane walks them -- a dependent 4-byte load per
+// block, ~50 ms for the 32,768 blocks of a 128 GiB frame -- and records payload offset,
+// size word and expected checksum per block.  info[0] = blocks found, info[1] = offset
+// behind the end mark (or where the walk stopped), info[2] = 0 or the LZ4HIP_ERR_* the
+// reader meets at that point (as int64), info[3] = 1 when max_blocks was too small.
+__global__ __launch_bounds__(64) void k_frame_index(const uint8_t *__restrict__ frame, size_t n,
+                                                    uint64_t first_off, uint32_t bs, int bsum,
+                                                    size_t max_blocks, uint64_t *__restrict__ off,
+                                                    uint32_t *__restrict__ sw,
+                                                    uint32_t *__restrict__ want,
+                                                    int64_t *__restrict__ info) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    size_t si = first_off, b = 0;
+    int64_t status = 0, full = 0;
+    for (;;) {
+        if (si > n || n - si < 4) {
+            status = LZ4HIP_ERR_FRAME;  // io.ErrUnexpectedEOF
+            break;
+        }
+        const uint32_t w = ld32(frame + si);
+        if (w == 0) {  // end mark: :295-298
+            si += 4;
+            break;
+        }
+        const uint32_t size = w & 0x7FFFFFFFu;
+        if (size > bs) {  // :301-304
+            status = LZ4HIP_ERR_BLOCK_SIZE;
+            break;
+        }
+        if (n - si - 4 < size || (bsum && n - si - 4 - size < 4)) {
+            status = LZ4HIP_ERR_FRAME;
+            break;
+        }
+        if (b == max_blocks) {
+            full = 1;
+            break;
+        }
+        off[b] = si + 4;
+        sw[b] = w;
+        si += 4 + (size_t)size;
+        if (bsum) {
+            want[b] = ld32(frame + si);
+            si += 4;
+        }
+        b++;
+    }
+    info[0] = (int64_t)b;
+    info[1] = (int64_t)si;
+    info[2] = status;
+    info[3] = full;
+}
+
+hipError_t launch_frame_index(const uint8_t *frame, size_t n, uint64_t first_off, uint32_t bs,
+                              int bsum, size_t max_blocks, uint64_t *off, uint32_t *sw,
+                              uint32_t *want, int64_t *info, hipStream_t st) {
+    hipLaunchKernelGGL(k_frame_index, dim3(1), dim3(64), 0, st, frame, n, first_off, bs, bsum,
+                       max_blocks, off, sw, want, info);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_blocks(const uint8_t *slots, size_t stride, const int32_t *out_len,
                               const uint64_t *flat_off, size_t nb, uint8_t *flat, hipStream_t st) {
     if (nb == 0) return hipSuccess;

@@ -675,6 +675,54 @@ int64_t lz4hip_frame_uncompress_lens(const uint8_t *src, size_t n, uint8_t *dst,
     return k;
 }
 
+// The content checksum of device-resident bytes, computed on the host.  The chain
+// v <- rol13(v + x*P2)*P1 is serial; one GPU lane steps it every ~15 cycles (2.4 GB/s), a host
+// core every ~5.  The bytes come down through two pinned buffers, one on the bus
+// while the other is hashed on the calling thread, so the call runs at the host's hash rate.
+int lz4hip_xxh32_stream_update_host(const void *d_src, size_t n, uint32_t *h_state, int first,
+                                    int final_piece, uint32_t *h_digest, void *stream) {
+    if (!h_state || (!d_src && n) || (final_piece && !h_digest))
+        return fail(LZ4HIP_ERR_ARG, "null pointer");
+    if (!final_piece && (n & 15))
+        return fail(LZ4HIP_ERR_ARG, "a non-final piece must be a multiple of 16 bytes");
+    constexpr size_t kPiece = 32u << 20;
+    struct Pinned {  // per calling thread, kept for the next call
+        uint8_t *buf[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+    };
+    static thread_local Pinned P;
+    for (int i = 0; i < 2; i++) {
+        if (!P.buf[i]) HIPCHK(hipHostMalloc((void **)&P.buf[i], kPiece, hipHostMallocDefault));
+        if (!P.ev[i]) HIPCHK(hipEventCreateWithFlags(&P.ev[i], hipEventDisableTiming));
+    }
+    HostXXH x;
+    if (!first) {
+        memcpy(x.v, h_state, 16);
+        x.total = (uint64_t)h_state[4] | ((uint64_t)h_state[5] << 32);
+        // a state handed over with totalLen 0 would be reset by the next Write
+        // (xxh32zero.go:59-61), exactly as the reference's would
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const uint8_t *src = static_cast<const uint8_t *>(d_src);
+    const size_t pieces = (n + kPiece - 1) / kPiece;
+    auto fetch = [&](size_t k) -> hipError_t {
+        const size_t at = k * kPiece, len = std::min(kPiece, n - at);
+        hipError_t e = hipMemcpyAsync(P.buf[k & 1], src + at, len, hipMemcpyDeviceToHost, st);
+        return e != hipSuccess ? e : hipEventRecord(P.ev[k & 1], st);
+    };
+    if (pieces) HIPCHK(fetch(0));
+    for (size_t k = 0; k < pieces; k++) {
+        if (k + 1 < pieces) HIPCHK(fetch(k + 1));
+        HIPCHK(hipEventSynchronize(P.ev[k & 1]));
+        x.write(P.buf[k & 1], std::min(kPiece, n - k * kPiece));
+    }
+    memcpy(h_state, x.v, 16);
+    h_state[4] = (uint32_t)x.total;
+    h_state[5] = (uint32_t)(x.total >> 32);
+    if (final_piece) *h_digest = x.sum32();
+    return LZ4HIP_OK;
+}
+
 lz4hip_stream *lz4hip_stream_create(uint32_t block_size, uint32_t flags, uint32_t level,
                                     size_t max_blocks) {
     if (flags & LZ4HIP_F_LEGACY) block_size = kLegacyBlock;

@@ -135,6 +135,42 @@ def xxh32_stream_update(src, n, state, first, final):
     return digest
 
 
+def xxh32_stream_update_host(src, n, state, first, final):
+    """The same chained checksum with the serial chain on a host core (the bytes come
+    down through pinned buffers); state: HOST int32[6] tensor.  Returns the digest as an
+    int when final, else None."""
+    import ctypes
+    digest = ctypes.c_uint32()
+    _lib.check(_lib.load().lz4hip_xxh32_stream_update_host(
+        src.data_ptr() if n else None, n, state.data_ptr(), int(first), int(final),
+        ctypes.addressof(digest) if final else None, _stream_ptr()))
+    return digest.value if final else None
+
+
+def frame_index(frame, n, first_off, block_size, block_checksums, max_blocks):
+    """Block index of a standard frame in device memory (lz4stream/block.go:279-317).
+    Returns (src_off int64 [max_blocks], size_words int32, want_xxh int32, info int64[4]);
+    info = [blocks, offset behind the end mark, status, max_blocks too small]."""
+    _u8(frame)
+    dev = frame.device
+    off = torch.empty(max(max_blocks, 1), dtype=torch.int64, device=dev)
+    sw = torch.empty(max(max_blocks, 1), dtype=torch.int32, device=dev)
+    want = torch.zeros(max(max_blocks, 1), dtype=torch.int32, device=dev)
+    info = torch.zeros(4, dtype=torch.int64, device=dev)
+    _lib.check(_lib.load().lz4hip_frame_index(frame.data_ptr(), n, first_off, block_size,
+                                              int(bool(block_checksums)), max_blocks, off.data_ptr(),
+                                              sw.data_ptr(), want.data_ptr(), info.data_ptr(),
+                                              _stream_ptr()))
+    return off, sw, want, info
+
+
+def pack_blocks(slots, stride, out_len, flat_off, nb, flat):
+    """Copies block b's out_len[b] bytes from slots + b*stride to flat + flat_off[b]."""
+    _lib.check(_lib.load().lz4hip_pack_blocks(slots.data_ptr(), stride, out_len.data_ptr(),
+                                              flat_off.data_ptr(), nb, flat.data_ptr(), _stream_ptr()))
+    return flat
+
+
 def frame_layout(result, n, block_size, nb, block_xxh=None, first_off=0):
     """Exclusive scan of entry sizes (lz4stream/block.go:254-276).
     Returns (entry_off [nb+1] int64, size_words [nb] int32)."""

@@ -263,23 +263,67 @@ def test_xxh32_stream_truncation_quirk(T, oracle):
 
 
 def test_sharded_frame_path_world1_device_ops(T, oracle):
-    """lz4_amd.shard with the real device ops (world size 1, RCCL backend):
-    exercises lz4hip_xxh32_stream_update and span assembly on the GPU."""
+    """lz4_amd.shard with the real device ops (world size 1, RCCL backend), both
+    directions: span assembly, the hosted and the device content-checksum chain, the
+    device-side block index (lz4hip_frame_index), batched decode + verification, the first
+    failing block, a ragged frame through lz4hip_pack_blocks."""
     import os
+    import struct
 
     import torch.distributed as dist
 
-    from lz4_amd import corpus, shard
+    from lz4_amd import _lib, corpus, shard
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29611")
     created = not dist.is_initialized()
     if created:
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=T.device("cuda", 0))
     try:
-        for n, flags in ((5 * 65536 + 999, 3), (4 * 65536, 3 | 8), (0, 2)):
+        bs = 1 << 16
+        for n, flags in ((5 * 65536 + 999, 3), (4 * 65536, 3 | 8), (0, 2), (300 * 65536 + 17, 1)):
             data = corpus.generate("mixed", 5, n) if n else np.zeros(0, dtype=np.uint8)
-            frame = shard.frame_compress_sharded(_dev(T, data), n, 1 << 16, flags, 0)
-            assert frame.cpu().numpy().tobytes() == oracle.frame_compress(data, 1 << 16, flags, 0)
+            want = oracle.frame_compress(data, bs, flags, 0)
+            for where in ("host", "device"):
+                frame = shard.frame_compress_sharded(_dev(T, data), n, bs, flags, 0,
+                                                     ops=shard.DeviceOps(checksum_on=where))
+                assert frame.cpu().numpy().tobytes() == want
+                flat, start, total = shard.frame_uncompress_sharded(frame, frame.numel(),
+                                                                    ops=shard.DeviceOps(checksum_on=where))
+                assert (start, total) == (0, n) and flat.cpu().numpy().tobytes() == data.tobytes()
+        # errors: first failing block in stream order, then the structural one behind it
+        data = corpus.generate("text", 3, 6 * bs)
+        frame = bytearray(oracle.frame_compress(data, bs, 3, 0))
+        offs, si = [], 7
+        while struct.unpack_from("<I", frame, si)[0]:
+            offs.append(si)
+            si += 8 + (struct.unpack_from("<I", frame, si)[0] & 0x7FFFFFFF)
+
+        def verdict(f):
+            with pytest.raises(shard.ShardError) as e:
+                shard.frame_uncompress_sharded(_dev(T, bytes(f)), len(f))
+            return e.value.code, e.value.block
+        bad = bytearray(frame)
+        bad[offs[4] + 4:offs[4] + 8] = b"\xff\xff\xff\xff"
+        assert verdict(bad)[1] == 4
+        bad[offs[2] - 1] ^= 1
+        assert verdict(bad) == (_lib.ERR_BLOCK_CHECKSUM, 1)
+        assert verdict(frame[:offs[5] + 100]) == (_lib.ERR_FRAME, 5)
+        bad = bytearray(frame)
+        bad[-1] ^= 1
+        assert verdict(bad) == (_lib.ERR_FRAME_CHECKSUM, None)
+        big = bytearray(frame)
+        big[offs[3]:offs[3] + 4] = struct.pack("<I", bs + 1)
+        assert verdict(big) == (_lib.ERR_BLOCK_SIZE, 3)
+        # ragged frame: short blocks mid-stream
+        raw = data.tobytes()
+        parts = [raw[:bs], raw[bs:bs + 1001], raw[bs + 1001:2 * bs + 77], raw[2 * bs + 77:3 * bs]]
+        f = bytearray(oracle.frame_header(bs, 2))
+        for p in parts:
+            k, c = oracle.CompressBlock(p, len(p))
+            f += struct.pack("<I", k) + c
+        f += struct.pack("<II", 0, oracle.ChecksumZero(b"".join(parts)))
+        flat, _, total = shard.frame_uncompress_sharded(_dev(T, bytes(f)), len(f))
+        assert total == 3 * bs and flat.cpu().numpy().tobytes() == b"".join(parts)
     finally:
         if created:
             dist.destroy_process_group()
