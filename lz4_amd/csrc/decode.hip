@@ -82,7 +82,7 @@ __device__ __forceinline__ Hdr parse_header(const uint8_t *ib, const int pos, co
 // == d means the history sits in memory right in front of d (single-block call, linked
 // frames); otherwise it is a separate dictionary (decode_other.go:109-121), and a match
 // that starts before d goes through the serial sequence decoder, which reads both parts.
-__device__ int decode_block(const uint8_t *__restrict__ in, const int n, uint8_t *d, const int dlen,
+__device__ __forceinline__ int decode_block(const uint8_t *__restrict__ in, const int n, uint8_t *d, const int dlen,
                              const int prefix, const uint8_t *hist_end, const int lane,
                              uint8_t *stage, uint8_t *ibuf, uint2 *desc) {
     const bool split = hist_end != d;
