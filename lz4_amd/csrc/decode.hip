@@ -22,7 +22,7 @@ namespace lz4hip {
 namespace {
 
 #ifndef LZ4HIP_DSETS
-#define LZ4HIP_DSETS 4
+#define LZ4HIP_DSETS 5
 #endif
 constexpr int kSets = LZ4HIP_DSETS;       // candidate positions per lane
 constexpr int kWin4 = kSets * kWave;      // compressed bytes per window
@@ -31,7 +31,7 @@ constexpr int kReach4 = kWin4 + 288;      // pass 1 and the literal copies read 
 // sets at most 64.  With more sets the link stops before a set that could overflow the
 // 64 token lanes.
 constexpr int kSetTokens = (kWave + 2) / 3;
-static_assert(kSets <= 4 && kWin4 + 275 < 1024, "descriptor fields: 9 + 9 + 10 bits");
+static_assert(kSets <= 8, "the token descriptor is a 16-bit window-relative position");
 static_assert(kReach4 + 16 <= kIn, "a refill must cover one window");
 
 struct Hdr {  // one candidate sequence header
@@ -76,15 +76,30 @@ __device__ __forceinline__ Hdr parse_header(const uint8_t *ib, const int pos, co
     return h;
 }
 
+// Pass 1 only needs to know where the sequence that would start at in[pos] ENDS: its
+// compressed length from the token and at most one length byte.  ok = "could be a plain
+// sequence" (lengths below 15+255 as far as this look goes, 18 bytes readable); the full
+// parse of the tokens that turn out to be real re-checks everything.
+__device__ __forceinline__ int light_seqlen(const uint8_t *ib, const int pos, const int n, bool &ok) {
+    uint32_t w0;
+    __builtin_memcpy(&w0, ib + pos, 4);  // inside the LDS buffer even past n (stale bytes, ok = false)
+    const uint32_t tok = w0 & 0xFFu;
+    const uint32_t b1 = (w0 >> 8) & 0xFFu;
+    const bool xl = (tok >> 4) == 0xFu;
+    ok = pos + 18 <= n && !(xl && b1 == 255u);
+    // 1 token + literal length byte + literals + 2 offset + match length byte
+    return 3 + (int)(tok >> 4) + (xl ? 1 + (int)b1 : 0) + ((tok & 0xFu) == 0xFu ? 1 : 0);
+}
+
 // `stage`: kStage bytes of LDS owned by this wave, 16-byte aligned; `ibuf`: kIn bytes
-// of LDS holding in[ibase, iend) (one coalesced refill per ~8 windows); `desc`: 64
-// token descriptors.  History before d: `prefix` bytes ending at `hist_end`.  hist_end
+// of LDS holding in[ibase, iend) (one coalesced refill per ~6 windows); `desc`: the
+// window-relative positions of up to 64 tokens.  History before d: `prefix` bytes ending at `hist_end`.  hist_end
 // == d means the history sits in memory right in front of d (single-block call, linked
 // frames); otherwise it is a separate dictionary (decode_other.go:109-121), and a match
 // that starts before d goes through the serial sequence decoder, which reads both parts.
 __device__ __forceinline__ int decode_block(const uint8_t *__restrict__ in, const int n, uint8_t *d, const int dlen,
                              const int prefix, const uint8_t *hist_end, const int lane,
-                             uint8_t *stage, uint8_t *ibuf, uint2 *desc) {
+                             uint8_t *stage, uint8_t *ibuf, uint16_t *desc) {
     const bool split = hist_end != d;
     int si = 0, di = 0, ibase = 0, iend = 0;
     for (;;) {
@@ -111,29 +126,21 @@ __device__ __forceinline__ int decode_block(const uint8_t *__restrict__ in, cons
         }
         const uint8_t *ib = ibuf - ibase;  // ib[p] = in[p] for ibase <= p < iend
 
-        // ---------------- pass 1: parse kSets x 64 candidate headers ----------------
+        // ---------------- pass 1: where would a sequence starting at each byte end ----------------
         // set j, lane l <-> position si + 64 j + l
-        uint32_t pk0[kSets], pk1[kSets];
+        int slen[kSets];
         uint64_t G[kSets];
-        {
-            const Hdr h = parse_header(ib, si + lane, n);
-            G[0] = ballot(h.ok);
-            pk0[0] = (uint32_t)h.off | ((uint32_t)h.lit << 16);
-            pk1[0] = (uint32_t)h.ml | ((uint32_t)(h.lpos - si) << 9) | ((uint32_t)(h.end - si) << 18);
+#pragma unroll
+        for (int j = 0; j < kSets; ++j) {
+            bool ok;
+            slen[j] = light_seqlen(ib, si + kWave * j + lane, n, ok);
+            G[j] = ballot(ok);
         }
         if (!(G[0] & 1)) {  // the sequence at si itself is not a plain one
             const int st = d2_serial_sequence(in, n, d, dlen, prefix, hist_end, si, di, lane);
             if (st < 0) return -1;
             if (st > 0) return di;
             continue;
-        }
-#pragma unroll
-        for (int j = 1; j < kSets; ++j) {
-            const int pos = si + kWave * j + lane;
-            const Hdr h = parse_header(ib, pos, n);
-            G[j] = ballot(h.ok);
-            pk0[j] = (uint32_t)h.off | ((uint32_t)h.lit << 16);
-            pk1[j] = (uint32_t)h.ml | ((uint32_t)(h.lpos - si) << 9) | ((uint32_t)(h.end - si) << 18);
         }
 
         // ---------------- link the real tokens (wave-uniform) ----------------
@@ -152,7 +159,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *__restrict__ in, cons
                 if (go) {
                     const uint64_t Gj = G[j];
                     // compressed length of the sequence that would start at my position
-                    const int seqlen = (int)(pk1[j] >> 18) - (kWave * j + lane);
+                    const int seqlen = slen[j];
                     int b = t - kWave * j;  // >= 0: a set is entered from the one before
                     if (b < kWave) {
                         // while (G[b]) { T |= 1 << b; b += seqlen[lane b]; if (b >= 64) break; }
@@ -191,18 +198,22 @@ __device__ __forceinline__ int decode_block(const uint8_t *__restrict__ in, cons
                 const int r = ntok + (int)__builtin_amdgcn_mbcnt_hi(
                                          (uint32_t)(Tj >> 32),
                                          __builtin_amdgcn_mbcnt_lo((uint32_t)Tj, 0u));
-                desc[r] = make_uint2(pk0[j], pk1[j]);
+                desc[r] = (uint16_t)(kWave * j + lane);
             }
             ntok += __builtin_popcountll(Tj);
         }
         lds_sync();
-        uint2 dsc = make_uint2(0u, 0u);
-        if (lane < ntok) dsc = desc[lane];
-        const int off = (int)(dsc.x & 0xFFFFu);
-        const int lit = (int)(dsc.x >> 16);
-        const int ml = (int)(dsc.y & 0x1FFu);
-        const int lpos = si + (int)((dsc.y >> 9) & 0x1FFu);
-        const int endrel = (int)(dsc.y >> 18);
+        // ---------------- full parse, token lanes only ----------------
+        Hdr h;
+        h.ok = false;
+        h.lit = h.ml = h.off = 0;
+        h.lpos = h.end = si;
+        if (lane < ntok) h = parse_header(ib, si + (int)desc[lane], n);
+        const int off = h.off;
+        const int lit = lane < ntok ? h.lit : 0;
+        const int ml = lane < ntok ? h.ml : 0;
+        const int lpos = h.lpos;
+        const int endrel = h.end - si;
         const int outlen = lit + ml;  // 0 in the lanes past ntok
 
         // exclusive scan of output lengths over the token lanes
@@ -211,7 +222,9 @@ __device__ __forceinline__ int decode_block(const uint8_t *__restrict__ in, cons
         const int mstart = myout + lit;   // offset of my match from di
         // the reference's bounds: literals and match fit dst, offset inside history
         // (with a separate dictionary, also a match that starts inside it: serial path)
-        const bool bad = lane < ntok && (di + mstart + ml > dlen ||
+        // (and a token the full parse does not accept as plain: 255-run match length, offset
+        // 0, too close to the end of the block -- the light look of pass 1 cannot see those)
+        const bool bad = lane < ntok && (!h.ok || di + mstart + ml > dlen ||
                                          off > di + mstart + (split ? 0 : prefix));
         const uint64_t B = ballot(bad);
         if (B) ntok = __builtin_ctzll(B);  // stop before the first violation
@@ -313,7 +326,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LZ4HIP_DECOD
     uint32_t prefix, const uint8_t *__restrict__ dict_end, int32_t *__restrict__ out_len) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kStage + 16];
     __shared__ __attribute__((aligned(16))) uint8_t ibuf[kIn + 16];
-    __shared__ uint2 desc[kWave];
+    __shared__ uint16_t desc[kWave];
     const int lane = lane_id();
     const size_t b = blockIdx.x;
     if (b >= nb) return;
@@ -356,7 +369,7 @@ __global__ __launch_bounds__(64) void k_decode_linked(const uint8_t *__restrict_
                                                        uint64_t *__restrict__ out_off) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kStage + 16];
     __shared__ __attribute__((aligned(16))) uint8_t ibuf[kIn + 16];
-    __shared__ uint2 desc[kWave];
+    __shared__ uint16_t desc[kWave];
     const int lane = lane_id();
     size_t total = 0;
     bool dead = false;
