@@ -76,6 +76,8 @@ __device__ __forceinline__ Hdr parse_header(const uint8_t *ib, const int pos, co
     return h;
 }
 
+constexpr int kNoSeq = 4096;  // "sequence length" of a position where no plain sequence starts
+
 // Pass 1 only needs to know where the sequence that would start at in[pos] ENDS: its
 // compressed length from the token and at most one length byte.  ok = "could be a plain
 // sequence" (lengths below 15+255 as far as this look goes, 18 bytes readable); the full
@@ -87,8 +89,9 @@ __device__ __forceinline__ int light_seqlen(const uint8_t *ib, const int pos, co
     const uint32_t b1 = (w0 >> 8) & 0xFFu;
     const bool xl = (tok >> 4) == 0xFu;
     ok = pos + 18 <= n && !(xl && b1 == 255u);
-    // 1 token + literal length byte + literals + 2 offset + match length byte
-    return 3 + (int)(tok >> 4) + (xl ? 1 + (int)b1 : 0) + ((tok & 0xFu) == 0xFu ? 1 : 0);
+    // 1 token + literal length byte + literals + 2 offset + match length byte; a position
+    // that cannot start a plain sequence gets kNoSeq, which throws the link out of its set
+    return ok ? 3 + (int)(tok >> 4) + (xl ? 1 + (int)b1 : 0) + ((tok & 0xFu) == 0xFu ? 1 : 0) : kNoSeq;
 }
 
 // `stage`: kStage bytes of LDS owned by this wave, 16-byte aligned; `ibuf`: kIn bytes
@@ -162,25 +165,24 @@ __device__ __forceinline__ int decode_block(const uint8_t *__restrict__ in, cons
                     const int seqlen = slen[j];
                     int b = t - kWave * j;  // >= 0: a set is entered from the one before
                     if (b < kWave) {
-                        // while (G[b]) { T |= 1 << b; b += seqlen[lane b]; if (b >= 64) break; }
-                        // hand-scheduled: seven scalar instructions per token (the compiler's
-                        // version of the same loop takes twelve)
+                        // do { T |= 1 << b; b += seqlen[lane b]; } while (b < 64);  T &= G;
+                        // Five scalar instructions per token, hand-scheduled.  A position
+                        // where no plain sequence starts has length kNoSeq: the walk marks
+                        // it, leaves the set with b >= kNoSeq, and the mark is taken back.
                         int tmp;
                         asm volatile(
                             "s_nop 1\n\t"  // the lane's seqlen was just written by the VALU
                             "1:\n\t"
-                            "s_bitcmp1_b64 %[G], %[b]\n\t"
-                            "s_cbranch_scc0 2f\n\t"
                             "s_bitset1_b64 %[T], %[b]\n\t"
                             "v_readlane_b32 %[tmp], %[sl], %[b]\n\t"
                             "s_add_i32 %[b], %[b], %[tmp]\n\t"
                             "s_cmp_lt_i32 %[b], 64\n\t"
-                            "s_cbranch_scc1 1b\n\t"
-                            "2:"
+                            "s_cbranch_scc1 1b"
                             : [T] "+s"(Tj), [b] "+s"(b), [tmp] "=&s"(tmp)
-                            : [G] "s"(Gj), [sl] "v"(seqlen)
+                            : [sl] "v"(seqlen)
                             : "scc");
-                        if (b < kWave) go = false;  // stopped at a position that is no plain token
+                        Tj &= Gj;
+                        if (b >= kNoSeq) go = false;  // stopped at a position that is no plain token
                     }
                     t = b + kWave * j;
                 }
