@@ -34,6 +34,19 @@ constexpr int kSrcBuf = LZ4HIP_SRCBUF;   // LDS bytes of buffered source per wav
 constexpr int kSrcReach = 84;   // phase A reads s[wbase-8, wbase+84)
 constexpr int kOutBuf = LZ4HIP_OUTBUF;   // LDS bytes in which a window's sequences are assembled (0: none)
 constexpr int kInUseWords = (1 << 16) / 32;  // block.go:57: inUse [1<<16/32]uint32
+#ifndef LZ4HIP_FAST_GATE
+#define LZ4HIP_FAST_GATE 0
+#endif
+#ifndef LZ4HIP_FAST_CANDLDS
+#define LZ4HIP_FAST_CANDLDS 0
+#endif
+#ifndef LZ4HIP_FAST_HIST
+#define LZ4HIP_FAST_HIST 8
+#endif
+constexpr int kSrcHist = LZ4HIP_FAST_HIST;      // source bytes behind the window kept at a refill (>= 8)
+static_assert(kSrcHist >= 8 && kSrcHist + 2 * kSrcReach <= kSrcBuf, "a refill must cover the window");
+constexpr bool kGateExt = LZ4HIP_FAST_GATE;     // extension loads only behind a verified candidate
+constexpr bool kCandLds = LZ4HIP_FAST_CANDLDS;  // candidates inside the LDS source buffer are read there
 
 // Lane `l` of `old` takes the wave-uniform value `v` (v_cmp + v_cndmask: the VOP3
 // form of v_writelane_b32 cannot take two SGPR operands on gfx9).
@@ -96,11 +109,26 @@ __device__ __forceinline__ int len_tail_size(int len) {  // bytes after the toke
     return len >= 0xF ? 1 + (len - 0xF) / 255 : 0;
 }
 
+// -DLZ4HIP_FAST_STATS (profiling builds only, tools/prof): lanes that issue a memory access,
+// by class, summed per block and added to uint64 counters behind the block counter in the
+// workspace tail: [1] table gathers, [2] 4-byte candidate verifies, [3] r0, [4] r1, [5] rb
+// extension loads, [6] table puts, [7] windows, [8] refill lines (64 B), [9] input bytes.
+#ifdef LZ4HIP_FAST_STATS
+#define FAST_STAT(i, v) stat[i] += (unsigned long long)(v)
+#else
+#define FAST_STAT(i, v)
+#endif
+
 template <bool kGlobal, typename TablePtr>
 __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const int n,
                                            uint8_t *__restrict__ d, const int dlen,
                                            TablePtr table, uint32_t *tag, uint8_t *sbuf,
-                                           uint8_t *obuf, uint32_t *inuse, const int lane) {
+                                           uint8_t *obuf, uint32_t *inuse, const int lane,
+                                           unsigned long long *stats = nullptr) {
+#ifdef LZ4HIP_FAST_STATS
+    unsigned long long stat[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    stat[9] = (unsigned long long)n;
+#endif
     const int bound = (int)compress_bound32((uint32_t)n);
     const bool not_compressible = dlen < bound;  // block.go:110
     {  // reset(): block.go:94,107
@@ -135,7 +163,7 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
         // ================= Phase A: lane l <-> position wbase + l =================
         const int wbase = si - 2;  // lane 0 is the position of a pending put(si-2)
         if (wbase + kSrcReach > se && se < n) {
-            sb = wbase - 8 < 0 ? 0 : (wbase - 8) & ~15;
+            sb = wbase - kSrcHist < 0 ? 0 : (wbase - kSrcHist) & ~15;
             const int cnt = n - sb < kSrcBuf ? n - sb : kSrcBuf;
             __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             for (int k = lane * 16; k < cnt; k += kWave * 16) {
@@ -148,6 +176,7 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
                 }
             }
             se = sb + cnt;
+            FAST_STAT(8, (cnt + 63) / 64);
             __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         const uint8_t *sl = sbuf - sb;  // sl[q] == s[q] for sb <= q < se
@@ -181,19 +210,44 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
         const bool bok = offok && ref >= 8;
         uint32_t cw = 0;
         uint64_t r0 = 0, q0 = 0, r1 = 0, q1 = 0, rb = 0, qb = 0;
-        if (offok) cw = ld32(s + ref);
-        if (f0ok) {
-            r0 = ld64(s + ref + 4);
+        // Candidate bytes: from the LDS source buffer when the candidate is recent enough to
+        // be in it (no memory request at all), else from global memory.
+        // (LDS reads are indexed from sbuf itself: `sl` is only valid while the arithmetic stays
+        // in the 32-bit LDS address space, and a pointer select would widen it to a flat one.)
+        auto cand64 = [&](int q) -> uint64_t {
+            uint64_t v = 0;
+            const bool in = kCandLds && q >= sb && q + 8 <= se;
+            if (in) __builtin_memcpy(&v, sbuf + (q - sb), 8);
+            if (!in) v = ld64(s + q);
+            return v;
+        };
+        if (offok) {
+            const bool in = kCandLds && ref >= sb && ref + 4 <= se;
+            if (in) __builtin_memcpy(&cw, sbuf + (ref - sb), 4);
+            if (!in) cw = ld32(s + ref);
+        }
+        // The extension bytes lie up to 8 bytes before and 20 behind the candidate: a third
+        // of them touch a second 64-byte line.  With kGateExt only the lanes whose 4 bytes
+        // verified fetch them (one more round trip for those lanes).
+        const bool want_ext = !kGateExt || (offok && cw == (uint32_t)x);
+        if (f0ok && want_ext) {
+            r0 = cand64(ref + 4);
             __builtin_memcpy(&q0, sl + p + 4, 8);
         }
-        if (f1ok) {
-            r1 = ld64(s + ref + 12);
+        if (f1ok && want_ext) {
+            r1 = cand64(ref + 12);
             __builtin_memcpy(&q1, sl + p + 12, 8);
         }
-        if (bok) {
-            rb = ld64(s + ref - 8);
+        if (bok && want_ext) {
+            rb = cand64(ref - 8);
             __builtin_memcpy(&qb, sl + p - 8, 8);
         }
+        FAST_STAT(7, 1);
+        FAST_STAT(1, __builtin_popcountll(ballot(kGlobal ? (valid && ((inuse[h >> 5] >> (h & 31)) & 1u)) : valid)));
+        FAST_STAT(2, __builtin_popcountll(ballot(offok)));
+        FAST_STAT(3, __builtin_popcountll(ballot(f0ok)));
+        FAST_STAT(4, __builtin_popcountll(ballot(f1ok)));
+        FAST_STAT(5, __builtin_popcountll(ballot(bok)));
         const bool m4 = offok && cw == (uint32_t)x;
         int mendv = p + kMinMatch;  // end of the match that starts at p (absolute)
         bool fmore = false;
@@ -411,6 +465,7 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
 
         // ---- close the window: write this window's puts to the table ----
         if (!failed && !finished) {
+            FAST_STAT(6, __builtin_popcountll(P));
             if ((P & ~CM) >> lane & 1) table[h] = pos16;  // distinct slots: one store
             uint64_t Pd = P & CM;  // may share a slot with an earlier put: position order
             while (Pd) {
@@ -451,6 +506,10 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
             ret = di + l_len;
         }
     }
+#ifdef LZ4HIP_FAST_STATS
+    if (stats && lane == 0)
+        for (int i = 1; i < 10; i++) atomicAdd(&stats[i], stat[i]);
+#endif
     return ret;
 }
 
@@ -506,8 +565,9 @@ __global__ __launch_bounds__(64) void k_fast_gtab(const uint8_t *__restrict__ sr
         const size_t left = n_total > start ? n_total - start : 0;
         const int n = (int)(left < block_size ? left : block_size);
         const int r = fast_block<true>(src + start, n, dst + b * dst_stride,
-                                                   block_dlen2(dst_mode, n, dst_len_x), table, tag,
-                                                   sbuf, obuf, inuse, lane);
+                                       block_dlen2(dst_mode, n, dst_len_x), table, tag, sbuf, obuf,
+                                       inuse, lane,
+                                       reinterpret_cast<unsigned long long *>(next_block));
         if (lane == 0) result[b] = r;
         __syncthreads();
         if (next_block)

@@ -152,7 +152,12 @@ int main(int argc, char **argv) {
     size_t ws_bytes = 0;
     const bool hc = what == "hc";
     ws_bytes = hc ? lz4hip_hc_workspace_bytes(nb) : lz4hip_fast_workspace_bytes(nb);
-    if (ws_bytes) CK(hipMalloc(&d_ws, ws_bytes));
+    if (const char *e = getenv("LZ4_PROF_SLOTS"))  // resident waves of the Fast kernel (wave sweep)
+        if (!hc && atoi(e) > 0) ws_bytes = (size_t)atoi(e) * 131072 + 256;
+    if (ws_bytes) {
+        CK(hipMalloc(&d_ws, ws_bytes));
+        CK(hipMemset((uint8_t *)d_ws + ws_bytes - 256, 0, 256));
+    }
     auto compress = [&] {
         if (hc)
             LZ(lz4hip_compress_hc_blocks(d_src, n, bs, level, LZ4HIP_DST_FRAME, d_comp, bs, d_res, d_ws,
@@ -174,6 +179,18 @@ int main(int argc, char **argv) {
     for (size_t b = 0; b < nb; b++) {
         if (res[b] > 0) c += (size_t)res[b];
         else c += bs, raw++;
+    }
+    if (what == "fast" && ws_bytes >= 256) {  // -DLZ4HIP_FAST_STATS builds: access counts by class
+        unsigned long long st[10];
+        CK(hipMemcpy(st, (uint8_t *)d_ws + ws_bytes - 256, sizeof st, hipMemcpyDeviceToHost));
+        if (st[7]) {
+            const double per = (double)st[9];  // bytes over all timed repetitions
+            fprintf(stderr,
+                    "{\"fast_stats_per_input_byte\":{\"table_gathers\":%.4f,\"candidate_verify\":%.4f,\"ext_r0\":%.4f,"
+                    "\"ext_r1\":%.4f,\"ext_rb\":%.4f,\"table_puts\":%.4f,\"refill_lines\":%.4f,\"bytes_per_window\":%.2f}}\n",
+                    st[1] / per, st[2] / per, st[3] / per, st[4] / per, st[5] / per, st[6] / per, st[8] / per,
+                    per / st[7]);
+        }
     }
     if (what != "decode") {
         printf("{\"what\":\"%s\",\"kind\":\"%s\",\"n\":%zu,\"bs\":%u,\"blocks\":%zu,\"raw_blocks\":%zu,\"c\":%zu,"

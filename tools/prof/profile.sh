@@ -39,8 +39,9 @@ if [ $WHAT = all ] || [ $WHAT = decode ]; then
   stats decode text 8 16 decode 3 || exit 1
   N=$((8<<30))
   pmc dec_mem "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" text 8 16 decode 1 || exit 1
+  pmc dec_ea "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" text 8 16 decode 1 || exit 1
   pmc dec_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" text 8 16 decode 1 || exit 1
-  for p in dec_mem dec_sq; do echo "# pass $p: prof_bench text 8 GiB, 64 KiB blocks, decode, 1 rep"; python3 $R/tools/prof/pmc_rows.py $O/pmc_$p $N; done > $O/pmc_decode_rows.txt
+  for p in dec_mem dec_ea dec_sq; do echo "# pass $p: prof_bench text 8 GiB, 64 KiB blocks, decode, 1 rep"; python3 $R/tools/prof/pmc_rows.py $O/pmc_$p $N; done > $O/pmc_decode_rows.txt
 fi
 if [ $WHAT = all ] || [ $WHAT = hc ]; then
   timeout -k 10 200 $B $TD binary 4 20 hc 1 131072 > $O/hc_binary.json || exit 1
