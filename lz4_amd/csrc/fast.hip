@@ -45,6 +45,13 @@ constexpr int kInUseWords = (1 << 16) / 32;  // block.go:57: inUse [1<<16/32]uin
 #endif
 constexpr int kSrcHist = LZ4HIP_FAST_HIST;      // source bytes behind the window kept at a refill (>= 8)
 static_assert(kSrcHist >= 8 && kSrcHist + 2 * kSrcReach <= kSrcBuf, "a refill must cover the window");
+#ifndef LZ4HIP_FAST_BITMAP
+#define LZ4HIP_FAST_BITMAP 1
+#endif
+// 1: the reference's in-use bitmap (8 KiB of LDS per wave; an unused slot costs no memory
+// request).  0: the global table is zeroed at every block start instead and every valid lane
+// gathers -- 3.5 KiB of LDS per wave, so twice as many waves fit a CU.
+constexpr bool kBitmap = LZ4HIP_FAST_BITMAP;
 constexpr bool kGateExt = LZ4HIP_FAST_GATE;     // extension loads only behind a verified candidate
 constexpr bool kCandLds = LZ4HIP_FAST_CANDLDS;  // candidates inside the LDS source buffer are read there
 
@@ -132,7 +139,12 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
     const int bound = (int)compress_bound32((uint32_t)n);
     const bool not_compressible = dlen < bound;  // block.go:110
     {  // reset(): block.go:94,107
-        if (kGlobal) {
+        if (kGlobal && !kBitmap) {
+            typedef uint4 __attribute__((may_alias)) uint4_a;
+            uint4_a *t4 = (uint4_a *)(table);
+            for (int k = lane; k < (1 << 16) * 2 / 16; k += kWave) t4[k] = make_uint4(0, 0, 0, 0);
+            __threadfence();
+        } else if (kGlobal) {
             // the reference's own scheme: clear the in-use bitmap (8 KiB, here in LDS), not the
             // table.  A get() of an unused slot is answered from the bitmap -- table value 0,
             // block.go:74-79 -- without touching memory, and the table is never zeroed.
@@ -187,7 +199,7 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
         const uint32_t h = hash6(x);
         uint32_t tv = 0;
         if (kGlobal) {
-            const bool used = valid && ((inuse[h >> 5] >> (h & 31)) & 1u);
+            const bool used = valid && (!kBitmap || ((inuse[h >> 5] >> (h & 31)) & 1u));
             if (used) tv = tab_load<kGlobal>(table, h);
         } else if (valid) {
             tv = tab_load<kGlobal>(table, h);
@@ -243,7 +255,7 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
             __builtin_memcpy(&qb, sl + p - 8, 8);
         }
         FAST_STAT(7, 1);
-        FAST_STAT(1, __builtin_popcountll(ballot(kGlobal ? (valid && ((inuse[h >> 5] >> (h & 31)) & 1u)) : valid)));
+        FAST_STAT(1, __builtin_popcountll(ballot(kGlobal && kBitmap ? (valid && ((inuse[h >> 5] >> (h & 31)) & 1u)) : valid)));
         FAST_STAT(2, __builtin_popcountll(ballot(offok)));
         FAST_STAT(3, __builtin_popcountll(ballot(f0ok)));
         FAST_STAT(4, __builtin_popcountll(ballot(f1ok)));
@@ -475,7 +487,7 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
                 if (lane == l) table[h] = pos16;
             }
             __asm__ volatile("" ::: "memory");
-            if (kGlobal && ((P >> lane) & 1)) atomicOr(&inuse[h >> 5], 1u << (h & 31));
+            if (kGlobal && kBitmap && ((P >> lane) & 1)) atomicOr(&inuse[h >> 5], 1u << (h & 31));
             __asm__ volatile("" ::: "memory");
         }
     }
@@ -545,7 +557,7 @@ __global__ __launch_bounds__(64) void k_fast_gtab(const uint8_t *__restrict__ sr
     __shared__ uint32_t tag[kTagN];
     __shared__ __attribute__((aligned(16))) uint8_t sbuf[kSrcBuf];
     __shared__ __attribute__((aligned(16))) uint8_t obuf[kOutBuf + 16];
-    __shared__ uint32_t inuse[kInUseWords];
+    __shared__ uint32_t inuse[kBitmap ? kInUseWords : 1];
     const int lane = lane_id();
     uint16_t *table = ws + (size_t)blockIdx.x * (1 << 16);
     // Blocks cost very different amounts of time (incompressible ones a fraction of
