@@ -262,6 +262,30 @@ def test_xxh32_stream_truncation_quirk(T, oracle):
     assert (int(dev.xxh32_stream(z, 1 << 32).item()) & 0xFFFFFFFF) == 0x02CC5D05
 
 
+@pytest.mark.parametrize("depth", [3, 64, 131072])
+def test_hc_window_clamp_and_long_range_repeats(T, oracle, depth):
+    """HC on 256 KiB blocks whose repeats sit just inside and just outside the 64 KiB window
+    (block.go:355-357 `si-next < winSize`, and the insert loop's clamp :394-405 after a match
+    longer than the window): long zero runs, a 70 KiB unit repeated, the same unit at 60 KiB."""
+    rng = np.random.default_rng(depth)
+    text = np.frombuffer(load("pg1661.txt"), dtype=np.uint8)
+    bs = 1 << 18
+    blocks = []
+    a70, a60 = text[:70 * 1024], text[100000:100000 + 60 * 1024]
+    blocks.append(np.concatenate([a70, a70, np.zeros(100 * 1024, np.uint8), a70[:bs - 240 * 1024]]))
+    blocks.append(np.concatenate([a60, a60, a60, a60, a60[:bs - 240 * 1024]]))
+    z = np.zeros(bs, np.uint8)
+    z[::65537 % 977] = 7
+    blocks.append(z)
+    noise = rng.integers(0, 256, bs, dtype=np.uint8)
+    noise[80000:80000 + 70000] = noise[1000:1000 + 70000]        # one 70 KB repeat at distance 79000 (> window)
+    noise[200000:200000 + 30000] = noise[150000:150000 + 30000]   # one at distance 50000 (inside)
+    blocks.append(noise)
+    data = np.concatenate([b[:bs] if b.size >= bs else np.concatenate([b, np.zeros(bs - b.size, np.uint8)])
+                           for b in blocks])
+    _check_blocks(T, oracle, data, bs, depth)
+
+
 def test_sharded_frame_path_world1_device_ops(T, oracle):
     """lz4_amd.shard with the real device ops (world size 1, RCCL backend), both
     directions: span assembly, the hosted and the device content-checksum chain, the

@@ -159,3 +159,30 @@ def test_host_entry_points_from_many_threads(oracle):
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+def test_quirk_paths_differential(oracle):
+    """Differential fuzz aimed at the reference's corner rules rather than at bulk data:
+    matches that run into the last mfLimit (12) / 5 bytes of a block (block.go:126,184-193,
+    363-372: Fast stops at sn = len-14 in 8-byte strides, HC's prefix loop may overshoot
+    sn-si by up to 7), every dst_len from "one byte short" to the bound (T5: (0,nil) vs error),
+    periods 1..9, Fast and three HC depths."""
+    import lz4_amd as lz
+    rng = np.random.default_rng(2024)
+    cases = []
+    for n in (17, 18, 19, 25, 26, 27, 28, 29, 33, 40, 41, 64, 65, 77, 130, 271, 300):
+        for period in (1, 2, 3, 4, 5, 7, 9):
+            unit = rng.integers(97, 123, period, dtype=np.uint8).tobytes()
+            head = rng.integers(0, 256, int(rng.integers(0, 9)), dtype=np.uint8).tobytes()
+            body = (head + unit * (n // period + 2))[:n]
+            if rng.integers(0, 3) == 0:          # break the run a few bytes before the end
+                k = n - 1 - int(rng.integers(0, 14))
+                body = body[:k] + bytes([body[k] ^ 0x55]) + body[k + 1:]
+            cases.append(body)
+    for src in cases[::2]:
+        n = len(src)
+        bound = lz.CompressBlockBound(n)
+        for dst_len in sorted({n // 3, n // 2, n - 1, n, n + 1, bound - 1, bound}):
+            for hc in (None, 1, 4, 65536):
+                assert _gpu_compress(lz, src, dst_len, hc) == _cpu_compress(oracle, src, dst_len, hc), \
+                    (n, dst_len, hc, src[:16])

@@ -323,3 +323,32 @@ def test_two_restatements_agree_on_random_small():
             for hc in (None, 7):
                 a, b = _both(src, dst_len, hc)
                 assert a == b, (n, alpha, dst_len, hc)
+
+
+def test_two_restatements_agree_on_quirk_paths():
+    """The corner rules compressed-byte parity depends on and bulk data rarely reaches:
+    periodic inputs whose matches run into the last 12 / 5 bytes (Fast's sn = len-14 stop in
+    8-byte strides, HC's prefix loop overshooting sn-si by up to 7), dst one byte short of the
+    bound, and HC's 64 KiB window clamp with repeats just inside / outside it.  (The same cases
+    run through the HIP kernels in tests/test_gpu_block.py::test_quirk_paths_differential and
+    tests/test_gpu_batch.py::test_hc_window_clamp_and_long_range_repeats.)"""
+    rng = np.random.default_rng(2024)
+    for n in (17, 19, 26, 27, 28, 29, 33, 41, 65, 130, 271):
+        for period in (1, 2, 3, 5, 9):
+            unit = rng.integers(97, 123, period, dtype=np.uint8).tobytes()
+            head = rng.integers(0, 256, int(rng.integers(0, 9)), dtype=np.uint8).tobytes()
+            src = (head + unit * (n // period + 2))[:n]
+            if rng.integers(0, 3) == 0:
+                k = n - 1 - int(rng.integers(0, 14))
+                src = src[:k] + bytes([src[k] ^ 0x55]) + src[k + 1:]
+            bnd = o.CompressBlockBound(n)
+            for dst_len in (n // 2, n - 1, n, bnd - 1, bnd):
+                for hc in (None, 1, 4, 65536):
+                    a, b = _both(src, dst_len, hc)
+                    assert a == b, (n, period, dst_len, hc)
+    text = load("pg1661.txt")
+    a70 = text[:70 * 1024]
+    src = a70 + a70 + bytes(20 * 1024) + a70[:8 * 1024]          # repeats at distance 70 KiB (> window)
+    for hc in (3, 64):
+        a, b = _both(src, None, hc)
+        assert a == b, hc
