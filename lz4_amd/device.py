@@ -27,14 +27,20 @@ _ws_cache = {}
 
 
 def fast_workspace(nb, device):
-    """Cached hash-table workspace of the Fast compressor for `device` (None when the
-    batch is small enough for the LDS-table kernel)."""
+    """Cached hash-table workspace of the Fast compressor (None when the batch is small
+    enough for the LDS-table kernel).  One per (device, stream): the workspace holds the
+    tables and the block counter of a launch, so two launches that may overlap -- different
+    streams -- must not share one.  A workspace that is outgrown is kept alive until the
+    stream it served has drained (record_stream), never freed under a running kernel."""
     need = _lib.load().lz4hip_fast_workspace_bytes(nb)
     if need == 0:
         return None
-    key = (device.type, device.index)
+    stream = torch.cuda.current_stream(device)
+    key = (device.type, device.index, stream.cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < need:
+        if ws is not None:
+            ws.record_stream(stream)
         ws = torch.empty(need, dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
     return ws
