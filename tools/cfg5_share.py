@@ -29,7 +29,7 @@ def timed(name, fn, nbytes=n):
 
 for rep in range(2):
     print("-- pass", rep, "(%d blocks of 4 MiB, %.2f GiB)" % (nb, n / 2**30))
-    comp, res = timed("Fast compress (k_fast3)", lambda: dev.compress_blocks(src, BS, 0))
+    comp, res = timed("Fast compress (k_fast_gtab)", lambda: dev.compress_blocks(src, BS, 0))
     xxh = timed("block checksums (k_xxh32_blocks)", lambda: dev.xxh32_blocks(src, BS, nb, n=n))
     cs = timed("content checksum (k_xxh32_stream)", lambda: dev.xxh32_stream(src, n))
     def assemble():
@@ -41,7 +41,7 @@ for rep in range(2):
     off, sw, frame, end = timed("layout scan + scatter", assemble)
     print("frame bytes %d (ratio %.4f)" % (end + 8, (end + 8) / n))
     src_off = (off[:nb] + 4).contiguous()
-    out, ol = timed("decode blocks (k_decode4)", lambda: dev.uncompress_blocks(frame, src_off, sw, BS))
+    out, ol = timed("decode blocks (k_decode)", lambda: dev.uncompress_blocks(frame, src_off, sw, BS))
     ok = bool((ol[:-1] == BS).all().item()) and int(ol[-1].item()) == n - (nb - 1) * BS
     ok = ok and torch.equal(out.view(-1)[:n], src)
     print("round trip exact:", ok)
