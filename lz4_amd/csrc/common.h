@@ -16,7 +16,7 @@ constexpr int kAdaptSkipLog = 7;
 // HC chain table: links per entry (hc.hip) and the bytes of one workspace slot
 // (hashTable u32[65536] + chainTable kHcLinks x u16 [65536]).
 #ifndef LZ4HIP_HC_LINKS
-#define LZ4HIP_HC_LINKS 16
+#define LZ4HIP_HC_LINKS 64
 #endif
 constexpr int kHcLinks = LZ4HIP_HC_LINKS;
 constexpr size_t kHcSlotBytes = 65536 * 4 + (size_t)65536 * kHcLinks * 2;

@@ -17,39 +17,63 @@ namespace lz4hip {
 
 // Per-slot workspace: hashTable u32[65536], then the chain table, kHcLinks u16 per entry.
 // The reference's chainTable[p & 0xffff] holds the previous position with p's hash
-// (block.go:382-383).  Here the entry holds the distances from p to the 1st .. kHcLinks-th
+// (block.go:382-383).  Here the entry holds the distances from p to the 1st .. 64th
 // previous positions of its chain, as u16 (0 = none, or 65536 or more away: the
-// reference's walk stops there anyway, `si-next < winSize`, :355).  Links of older
-// positions never change, so links 2.. are link 1 plus the links read from the previous
-// head's entry at insertion time.  A walk then costs one dependent fetch per kHcLinks
-// candidates instead of one per candidate, in the same candidate order.
+// reference's walk stops there anyway, `si-next < winSize`, :355) -- one 128-byte line, one
+// link per lane.  Links of older positions never change, so links 2.. are link 1 plus the
+// links of the previous head's entry at insertion time.  A walk then costs ONE dependent
+// fetch per 64 candidates instead of one per candidate, in the same candidate order, and
+// the fetch of the next entry is in flight while the current 64 candidates are compared.
+static_assert(kHcLinks == kWave, "one link per lane");
 constexpr int kHcSlotWords = (1 << 16) + (1 << 16) * kHcLinks / 2;
 
-// chainTable[p] = hashTable[hh]; hashTable[hh] = p  (block.go:382-383,401-402), by the
-// whole wave: lane j < kHcLinks builds and stores link j.
+// Links of a position inserted behind `head` (distance d0 > 0, inside the window), given
+// lane j-1's link of head's entry in `inh_prev` (lane 0: unused): link 0 = d0, link j = d0 +
+// head's link j-1 while that stays inside the window.
+__device__ __forceinline__ uint32_t hc_link(uint32_t d0, uint32_t inh_prev, int lane) {
+    if (lane == 0) return d0;
+    return (inh_prev != 0 && d0 + inh_prev < (uint32_t)kWinSize) ? d0 + inh_prev : 0u;
+}
+
+// chainTable[p] = hashTable[hh]; hashTable[hh] = p  (block.go:382-383,401-402) for one
+// position, by the whole wave, reading head and head's entry (two dependent fetches; the
+// search path below avoids them by reusing what the search has just read).
 __device__ __forceinline__ void hc_insert(uint32_t *hash_table, uint16_t *chain_table, uint32_t hh,
                                           int p, int lane) {
     const int head = (int)hash_table[hh];
-    if (lane < kHcLinks) {
-        uint32_t l = 0;
-        if (head > 0 && p - head < kWinSize) {
-            const uint32_t d0 = (uint32_t)(p - head);
-            if (lane == 0) {
-                l = d0;
-            } else {
-                const uint32_t hl = chain_table[(size_t)(head & kWinMask) * kHcLinks + lane - 1];
-                if (hl != 0 && d0 + hl < (uint32_t)kWinSize) l = d0 + hl;
-            }
-        }
-        chain_table[(size_t)(p & kWinMask) * kHcLinks + lane] = (uint16_t)l;
+    uint32_t l = 0;
+    if (head > 0 && p - head < kWinSize) {
+        uint32_t hl = 0;
+        if (lane > 0) hl = chain_table[(size_t)(head & kWinMask) * kHcLinks + lane - 1];
+        l = hc_link((uint32_t)(p - head), hl, lane);
     }
+    chain_table[(size_t)(p & kWinMask) * kHcLinks + lane] = (uint16_t)l;
     __syncthreads();  // every lane has read the old head
     if (lane == 0) hash_table[hh] = (uint32_t)p;
 }
 
-// Prefix length of block.go:361-372 for one candidate (lane-private loop).
+// Prefix length of block.go:361-372 for one candidate (lane-private loop): 8-byte strides
+// while ml < lim, so ml may overshoot lim by up to 7.  Most candidates differ inside the
+// first stride; the few long ones decide how long the wave waits, so after the first stride
+// the compare runs 32 bytes per round trip (four strides in flight) while 32 more bytes are
+// inside lim -- the same first differing byte is found either way.
 __device__ __forceinline__ int hc_prefix_len(const uint8_t *s, int next, int si, int lim) {
     int ml = 0;
+    {
+        const uint64_t x = ld64(s + next) ^ ld64(s + si);
+        if (x != 0) return __builtin_ctzll(x) >> 3;
+        ml = 8;
+    }
+    while (ml + 32 <= lim) {
+        const uint8_t *a = s + next + ml, *b = s + si + ml;
+        const uint64_t x0 = ld64(a) ^ ld64(b), x1 = ld64(a + 8) ^ ld64(b + 8);
+        const uint64_t x2 = ld64(a + 16) ^ ld64(b + 16), x3 = ld64(a + 24) ^ ld64(b + 24);
+        if (x0) return ml + (__builtin_ctzll(x0) >> 3);
+        if (x1) return ml + 8 + (__builtin_ctzll(x1) >> 3);
+        if (x2) return ml + 16 + (__builtin_ctzll(x2) >> 3);
+        if (x3) return ml + 24 + (__builtin_ctzll(x3) >> 3);
+        ml += 32;
+    }
     while (ml < lim) {
         const uint64_t x = ld64(s + next + ml) ^ ld64(s + si + ml);
         if (x == 0) {
@@ -71,16 +95,17 @@ __device__ __forceinline__ int wave_max(int v) {
 }
 
 // Inserts positions p0 .. p0+n-1 in order (block.go:394-405 without the window clamp:
-// every position's 4-byte value is then its own bytes), 64 per round, all lanes at once.
-// Sequential semantics: each position links to the latest earlier position with its
-// hash -- inside the round if there is one, else the table's head -- and the table keeps
-// the last one.  Lanes without an earlier twin gather head and head's links together;
-// lanes with a twin take the twin's position and (twin's links + distance), resolved in
-// dependency order with shuffles: as many steps as the longest same-hash run, no memory
-// round trip inside (a run of equal bytes resolves in registers).
+// every position's 4-byte value is then its own bytes), 64 per round.  Sequential
+// semantics: each position links to the latest earlier position with its hash -- inside the
+// round if there is one (its "twin"), else the table's head -- and the table keeps the last
+// one.  Lane i first gathers head and head's entry of position i into row i of an LDS
+// staging area (all 64 positions' fetches in flight together).  Then the positions are
+// finished in order, the wave one link per lane: from its own staged row, or from the twin's
+// FINISHED row (a run of equal bytes resolves at LDS latency, no memory round trip), and each
+// finished row goes out as one 128-byte store.
 __device__ __forceinline__ void hc_insert_run(uint32_t *hash_table, uint16_t *chain_table,
                                               const uint8_t *__restrict__ s, int p0, int n,
-                                              int lane) {
+                                              int lane, uint16_t *rows) {
     typedef uint4 __attribute__((may_alias)) uint4_a;
     for (int base = 0; base < n; base += kWave) {
         const int cnt = n - base < kWave ? n - base : kWave;
@@ -96,70 +121,34 @@ __device__ __forceinline__ void hc_insert_run(uint32_t *hash_table, uint16_t *ch
                 if (lane < i) later = true;
             }
         }
-        // d[k]: my links, two u16 per register (the entry's memory image)
-        uint32_t d[kHcLinks / 2];
-#pragma unroll
-        for (int k = 0; k < kHcLinks / 2; k++) d[k] = 0;
-        bool done = !act;
-        uint32_t shift = 0;  // what to add to the links I inherit
+        // distance to the position I link to: the twin, or the table's head (0: none)
+        int d0 = twin >= 0 ? lane - twin : 0;
         if (act && twin < 0) {
             const int head = (int)hash_table[hh];
             if (head > 0 && p - head < kWinSize) {
-                shift = (uint32_t)(p - head);
+                d0 = p - head;
                 const uint4_a *e = (const uint4_a *)(chain_table + (size_t)(head & kWinMask) * kHcLinks);
+                uint4_a *r = (uint4_a *)(rows + lane * kHcLinks);
 #pragma unroll
-                for (int q = 0; q < kHcLinks / 8; q++) {
-                    const uint4 v = e[q];
-                    d[4 * q] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w;
-                }
+                for (int q = 0; q < kHcLinks / 8; q++) r[q] = e[q];
             }
         }
-        // lanes with a twin inherit the twin's FINAL links: resolved in dependency order
-        // with shuffles (as many steps as the longest same-hash run of the round)
-        // first turn "inherited links" into "my links" for the lanes that read the table
-        auto finish = [&](uint32_t sh) {
-            // my link 0 = sh; my link j = sh + inherited link j-1 (while present and in window)
-            uint32_t prev = sh;  // value going into the low half of d[0]
-            bool alive = sh != 0;
-#pragma unroll
-            for (int k = 0; k < kHcLinks / 2; k++) {
-                const uint32_t in_lo = d[k] & 0xFFFFu, in_hi = d[k] >> 16;  // inherited links 2k, 2k+1
-                const uint32_t lo = alive ? prev : 0;                        // my link 2k
-                uint32_t hi = 0;                                             // my link 2k+1 = sh + inherited 2k
-                if (alive && in_lo != 0 && sh + in_lo < (uint32_t)kWinSize) hi = sh + in_lo;
-                else alive = false;
-                // my link 2k+2 = sh + inherited 2k+1
-                uint32_t nxt = 0;
-                if (alive && in_hi != 0 && sh + in_hi < (uint32_t)kWinSize) nxt = sh + in_hi;
-                else alive = false;
-                d[k] = lo | (hi << 16);
-                prev = nxt;
+        __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        for (int i = 0; i < cnt; i++) {
+            const int t = __builtin_amdgcn_readlane(twin, i);
+            const uint32_t d = (uint32_t)__builtin_amdgcn_readlane(d0, i);
+            uint32_t l = 0;
+            if (d != 0) {
+                uint32_t inh = 0;
+                if (lane > 0) inh = rows[(t >= 0 ? t : i) * kHcLinks + lane - 1];
+                l = hc_link(d, inh, lane);
             }
-        };
-        if (act && twin < 0) {
-            finish(shift);
-            done = true;
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // row i was read before it is overwritten
+            rows[i * kHcLinks + lane] = (uint16_t)l;
+            chain_table[(size_t)((p0 + base + i) & kWinMask) * kHcLinks + lane] = (uint16_t)l;
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // a later twin reads this row
         }
-        while (ballot(!done)) {
-            const int src = twin < 0 ? lane : twin;
-            uint32_t t[kHcLinks / 2];
-#pragma unroll
-            for (int k = 0; k < kHcLinks / 2; k++) t[k] = (uint32_t)__shfl((int)d[k], src);
-            const bool tdone = __shfl((int)done, src) != 0;
-            if (!done && tdone) {
-#pragma unroll
-                for (int k = 0; k < kHcLinks / 2; k++) d[k] = t[k];
-                finish((uint32_t)(lane - twin));
-                done = true;
-            }
-        }
-        if (act) {
-            uint4_a *e = (uint4_a *)(chain_table + (size_t)(p & kWinMask) * kHcLinks);
-#pragma unroll
-            for (int q = 0; q < kHcLinks / 8; q++)
-                e[q] = make_uint4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
-            if (!later) hash_table[hh] = (uint32_t)p;
-        }
+        if (act && !later) hash_table[hh] = (uint32_t)p;
         __syncthreads();  // the next round gathers what this one stored
     }
 }
@@ -171,6 +160,7 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                                                     int32_t *__restrict__ result,
                                                     uint32_t *__restrict__ ws, size_t nb,
                                                     uint32_t *__restrict__ next_block) {
+    __shared__ __attribute__((aligned(16))) uint16_t rows[kWave * kHcLinks];  // hc_insert_run's staging
     const int lane = lane_id();
     uint32_t *hash_table = ws + (size_t)blockIdx.x * kHcSlotWords;
     uint16_t *chain_table = reinterpret_cast<uint16_t *>(hash_table + (1 << 16));
@@ -211,6 +201,7 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
             uint32_t match = ld32(s + si);
             const uint32_t h = hash4(match);
             int m_len = 0, offset = 0;
+            uint32_t my_link = 0;  // lane j: link j of si's own chain entry (from the first batch)
             {
                 const int lim = sn - si;
                 int next = (int)hash_table[h];
@@ -219,44 +210,37 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                 // strictly longer candidate replaces the winner (:373), so the walk can
                 // stop once that maximum is reached: the rest of the chain changes nothing.
                 const int ml_max = (lim + 7) & ~7;
-                while (tries > 0 && next > 0 && si - next < kWinSize && m_len < ml_max) {
-                    // collect up to 64 chain entries, one per lane: `next` itself, then up
-                    // to kHcLinks per fetched chain entry (lane j < kHcLinks loads link j)
-                    int mine = 0;
-                    if (lane == 0) mine = next;
-                    int cnt = 1;
-                    tries--;
-                    int cur = next;
+                auto in_window = [&](int q) { return q > 0 && si - q < kWinSize; };
+                // `l`: lane j's link of cur's entry, fetched one batch ahead
+                uint32_t l = 0;
+                if (in_window(next)) l = chain_table[(size_t)(next & kWinMask) * kHcLinks + lane];
+                bool first = true;
+                while (tries > 0 && in_window(next) && m_len < ml_max) {
+                    // one batch = cur itself (lane 0) and cur's links 0..62 (lanes 1..63);
+                    // link 63 starts the next batch
+                    const int cur = next;
+                    const uint32_t lk = (uint32_t)__shfl_up((int)l, 1);  // lane k: link k-1
+                    const int mine = lane == 0 ? cur : cur - (int)lk;
+                    const bool valid = lane == 0 || (lk != 0 && si - mine < kWinSize);
+                    if (first) {
+                        // chainTable[si] = hashTable[h] (:382): si's entry is the distances to
+                        // exactly these candidates -- no second look at the table needed
+                        my_link = hc_link((uint32_t)(si - cur), lk, lane);
+                        first = false;
+                    }
+                    // links are ordered and prefix-complete: the valid lanes are 0..nv-1
+                    const int nv = __builtin_popcountll(ballot(valid));
+                    int cnt = nv;
+                    if ((uint32_t)cnt > tries) cnt = (int)tries;
+                    tries -= (uint32_t)cnt;
                     next = 0;
-                    bool resume = false;  // batch ended right after a last link: fetch once more
-                    while (cnt < kWave && tries > 0) {
-                        int l = 0;
-                        if (lane < kHcLinks) l = chain_table[(size_t)(cur & kWinMask) * kHcLinks + lane];
-                        // links are ordered and prefix-complete: count the ones inside the window
-                        const uint64_t okm = ballot(lane < kHcLinks && l != 0 && si - (cur - l) < kWinSize);
-                        const int nv = __builtin_popcountll(okm);
-                        int nt = nv;
-                        if (nt > kWave - cnt) nt = kWave - cnt;
-                        if ((uint32_t)nt > tries) nt = (int)tries;
-                        const int k = lane - cnt;
-                        const int lk = __shfl(l, k & (kWave - 1));
-                        if (k >= 0 && k < nt) mine = cur - lk;
-                        cnt += nt;
-                        tries -= (uint32_t)nt;
-                        if (nt < kHcLinks) {
-                            // chain over (nt == nv), depth spent, or out of lanes: then the
-                            // first link not taken starts the next batch
-                            if (nt < nv && tries > 0) next = cur - (int)rfl((uint32_t)__shfl(l, nt));
-                            resume = false;
-                            break;
-                        }
-                        cur -= (int)rfl((uint32_t)__shfl(l, kHcLinks - 1));
-                        resume = true;
+                    if (nv == kWave && tries > 0) {
+                        const uint32_t l63 = rfl((uint32_t)__shfl((int)l, kWave - 1));
+                        if (l63 != 0) next = cur - (int)l63;  // window check: loop condition
                     }
-                    if (resume && tries > 0) {
-                        const int l = chain_table[(size_t)(cur & kWinMask) * kHcLinks];
-                        if (l != 0) next = cur - l;  // window check: loop condition
-                    }
+                    // the next entry's fetch flies while this batch is compared
+                    uint32_t l_next = 0;
+                    if (in_window(next)) l_next = chain_table[(size_t)(next & kWinMask) * kHcLinks + lane];
                     int ml = 0;
                     if (lane < cnt) ml = hc_prefix_len(s, mine, si, lim);
                     // winner: max ml, ties to the earliest chain entry (lowest lane)
@@ -266,9 +250,13 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                         m_len = best >> 6;
                         offset = si - __shfl(mine, 63 - (best & 63));
                     }
+                    l = l_next;
                 }
             }
-            hc_insert(hash_table, chain_table, h, si, lane);
+            // hc_insert(si): the entry was derived above (all zero when there was no head
+            // inside the window); the head moves to si
+            chain_table[(size_t)(si & kWinMask) * kHcLinks + lane] = (uint16_t)my_link;
+            if (lane == 0) hash_table[h] = (uint32_t)si;
             __syncthreads();
 
             if (m_len == 0) {  // :386-389
@@ -282,7 +270,7 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                 if (wsn > p) p = wsn;
                 const int end = si + m_len;
                 if (wsn <= si + 1) {
-                    hc_insert_run(hash_table, chain_table, s, p, end - p, lane);
+                    hc_insert_run(hash_table, chain_table, s, p, end - p, lane, rows);
                 } else {
                     // The reference rolls the 4-byte value from the one at si
                     // (:399-400).  When the window clamp skips positions (match
