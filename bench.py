@@ -74,7 +74,9 @@ def main():
     if one_dev:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     else:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        import datetime
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device,
+                                timeout=datetime.timedelta(minutes=5))
 
     def barrier():
         torch.cuda.synchronize()
@@ -207,48 +209,51 @@ def main():
     # ---- cfg5 frame path through lz4_amd.shard (outside the headline's timed region) ----
     frame_path = None
     if args.frame_gib > 0:
-        from lz4_amd import shard
-        BS_F = 1 << 22
-        share = min(int(args.frame_gib * (1 << 30)), n) // BS_F * BS_F
-        src_f = mixed[:share]               # this rank's block range of the stream
-        n_total = share * world
-        del comp, out
-        torch.cuda.empty_cache()
-        fp = {"write_GBps": {}, "read_GBps": {}, "phases_s": {}}
-        ok_rt = True
-        for label, flags in (("no_content_checksum", 1), ("content_checksum", 3)):
-            ws, rs = {}, {}
-            shard.frame_compress_sharded(src_f[:BS_F], BS_F * world, BS_F, flags, 0)   # warm-up
-            barrier()
-            t0 = time.perf_counter()
-            frame = shard.frame_compress_sharded(src_f, n_total, BS_F, flags, 0, stats=ws)
-            barrier()
-            t1 = time.perf_counter()
-            flat, _, tot = shard.frame_uncompress_sharded(frame, frame.numel() if rank == 0 else 0, stats=rs)
-            barrier()
-            t2 = time.perf_counter()
-            ok_rt &= tot == n_total and torch.equal(flat, src_f)
-            fp["write_GBps"][label] = round(n_total / (t1 - t0) / 1e9, 3)
-            fp["read_GBps"][label] = round(n_total / (t2 - t1) / 1e9, 3)
-            fp["phases_s"][label] = {"write": {k: round(v, 4) for k, v in ws.items() if k.endswith("_s")},
-                                     "read": {k: round(v, 4) for k, v in rs.items() if k.endswith("_s")}}
-            if rank == 0 and flags == 1:
-                gb = ws.get("gather_bytes", 0)
-                peak = 153.0 * min(world - 1, 7)
-                fp["gather"] = {"bytes": gb, "seconds": round(ws.get("gather_s", 0.0), 4),
-                                "GBps": round(gb / max(ws.get("gather_s", 0.0), 1e-9) / 1e9, 2) if gb else 0.0,
-                                "peak_GBps": peak,
-                                "note": "spans received straight into the frame, one xGMI link per sender "
-                                        "(7 x 153 GB/s inbound at the root)"}
-                fp["frame_bytes"] = int(frame.numel())
-            del frame, flat
-        flag = torch.tensor([1 if ok_rt else 0], dtype=torch.int64, device="cpu" if one_dev else device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        fp["round_trip_equals_source"] = bool(flag.item())
-        fp["workload"] = ("cfg5 share: %.2f GiB/GPU of the mixed corpus, 4MB blocks, xxh32 block checksums, "
-                          "Writer + Reader through lz4_amd.shard; content checksum chain on the host"
-                          % (share / 2**30))
-        frame_path = fp
+        try:
+            from lz4_amd import shard
+            BS_F = 1 << 22
+            share = min(int(args.frame_gib * (1 << 30)), n) // BS_F * BS_F
+            src_f = mixed[:share]               # this rank's block range of the stream
+            n_total = share * world
+            del comp, out
+            torch.cuda.empty_cache()
+            fp = {"write_GBps": {}, "read_GBps": {}, "phases_s": {}}
+            ok_rt = True
+            for label, flags in (("no_content_checksum", 1), ("content_checksum", 3)):
+                ws, rs = {}, {}
+                shard.frame_compress_sharded(src_f[:BS_F], BS_F * world, BS_F, flags, 0)   # warm-up
+                barrier()
+                t0 = time.perf_counter()
+                frame = shard.frame_compress_sharded(src_f, n_total, BS_F, flags, 0, stats=ws)
+                barrier()
+                t1 = time.perf_counter()
+                flat, _, tot = shard.frame_uncompress_sharded(frame, frame.numel() if rank == 0 else 0, stats=rs)
+                barrier()
+                t2 = time.perf_counter()
+                ok_rt &= tot == n_total and torch.equal(flat, src_f)
+                fp["write_GBps"][label] = round(n_total / (t1 - t0) / 1e9, 3)
+                fp["read_GBps"][label] = round(n_total / (t2 - t1) / 1e9, 3)
+                fp["phases_s"][label] = {"write": {k: round(v, 4) for k, v in ws.items() if k.endswith("_s")},
+                                         "read": {k: round(v, 4) for k, v in rs.items() if k.endswith("_s")}}
+                if rank == 0 and flags == 1:
+                    gb = ws.get("gather_bytes", 0)
+                    peak = 153.0 * min(world - 1, 7)
+                    fp["gather"] = {"bytes": gb, "seconds": round(ws.get("gather_s", 0.0), 4),
+                                    "GBps": round(gb / max(ws.get("gather_s", 0.0), 1e-9) / 1e9, 2) if gb else 0.0,
+                                    "peak_GBps": peak,
+                                    "note": "spans received straight into the frame, one xGMI link per sender "
+                                            "(7 x 153 GB/s inbound at the root)"}
+                    fp["frame_bytes"] = int(frame.numel())
+                del frame, flat
+            flag = torch.tensor([1 if ok_rt else 0], dtype=torch.int64, device="cpu" if one_dev else device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            fp["round_trip_equals_source"] = bool(flag.item())
+            fp["workload"] = ("cfg5 share: %.2f GiB/GPU of the mixed corpus, 4MB blocks, xxh32 block checksums, "
+                              "Writer + Reader through lz4_amd.shard; content checksum chain on the host"
+                              % (share / 2**30))
+            frame_path = fp
+        except Exception as e:  # the headline line must survive a failure of this extra section
+            frame_path = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         total = args.steps * 2 * n * world
