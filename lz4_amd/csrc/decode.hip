@@ -166,21 +166,25 @@ __device__ __forceinline__ int decode_block(const uint8_t *__restrict__ in, cons
                     int b = t - kWave * j;  // >= 0: a set is entered from the one before
                     if (b < kWave) {
                         // do { T |= 1 << b; b += seqlen[lane b]; } while (b < 64);  T &= G;
-                        // Five scalar instructions per token, hand-scheduled.  A position
-                        // where no plain sequence starts has length kNoSeq: the walk marks
-                        // it, leaves the set with b >= kNoSeq, and the mark is taken back.
+                        // Four scalar instructions per token, hand-scheduled.  b is kept
+                        // biased by -64 as an unsigned number: its low six bits are still the
+                        // lane (s_bitset1 and v_readlane look at no others), and the add's
+                        // carry-out is "b has left the set", so no compare is needed.  A
+                        // position where no plain sequence starts has length kNoSeq: the walk
+                        // marks it, leaves the set with b >= kNoSeq, and the mark is taken back.
                         int tmp;
+                        uint32_t bb = (uint32_t)b - (uint32_t)kWave;
                         asm volatile(
                             "s_nop 1\n\t"  // the lane's seqlen was just written by the VALU
                             "1:\n\t"
                             "s_bitset1_b64 %[T], %[b]\n\t"
                             "v_readlane_b32 %[tmp], %[sl], %[b]\n\t"
-                            "s_add_i32 %[b], %[b], %[tmp]\n\t"
-                            "s_cmp_lt_i32 %[b], 64\n\t"
-                            "s_cbranch_scc1 1b"
-                            : [T] "+s"(Tj), [b] "+s"(b), [tmp] "=&s"(tmp)
+                            "s_add_u32 %[b], %[b], %[tmp]\n\t"
+                            "s_cbranch_scc0 1b"
+                            : [T] "+s"(Tj), [b] "+s"(bb), [tmp] "=&s"(tmp)
                             : [sl] "v"(seqlen)
                             : "scc");
+                        b = (int)(bb + (uint32_t)kWave);
                         Tj &= Gj;
                         if (b >= kNoSeq) go = false;  // stopped at a position that is no plain token
                     }
