@@ -17,10 +17,20 @@ import shutil
 
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
-FILES = """Mark.Twain-Tom.Sawyer.txt Mark.Twain-Tom.Sawyer.txt.lz4 bzImage_lz4_isolated
-bzImage_lz4_isolated.lz4 e.txt e.txt.lz4 empty.txt gettysburg.txt gettysburg.txt.lz4 issue51.data
-malformed.block.lz4 pg1661.txt pg1661.txt.lz4 pg_control.tar pg_control.tar.lz4 pi.txt pi.txt.lz4
-random.data random.data.lz4 repeat.txt repeat.txt.lz4 upperbound.data""".split()
+FILES = """Mark.Twain-Tom.Sawyer.txt Mark.Twain-Tom.Sawyer.txt.lz4
+Mark.Twain-Tom.Sawyer_long.txt.lz4 Mark.Twain-Tom.Sawyer_linked.txt.lz4 bzImage_lz4_isolated
+bzImage_lz4_isolated.lz4 e.txt e.txt.lz4 empty.txt gettysburg.txt gettysburg.txt.lz4 issue102.data
+issue51.data malformed.block.lz4 pg1661.txt pg1661.txt.lz4 pg_control.tar pg_control.tar.lz4 pi.txt
+pi.txt.lz4 random.data random.data.lz4 repeat.txt repeat.txt.lz4 upperbound.data""".split()
+# (Mark.Twain-Tom.Sawyer_long.txt itself, issue43.data and vmlinux_LZ4_19377[.lz4] are listed in the
+# reference's .MISSING_LARGE_BLOBS and absent from the checkout: the _long / _linked frames are
+# checked through their content checksum and against each other, tests/kats.py LONG_FRAMES.)
+
+def check():
+    """Every committed fixture is listed above, and nothing listed is missing."""
+    have = sorted(os.listdir(os.path.join(HERE, "testdata")))
+    assert have == sorted(FILES), sorted(set(have) ^ set(FILES))
+
 
 if __name__ == "__main__":
     os.makedirs(os.path.join(HERE, "testdata"), exist_ok=True)

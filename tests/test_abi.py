@@ -165,3 +165,12 @@ def test_frame_parse_header_host_only():
 def oracle_xxh32(b):
     from oracle import pyoracle as o
     return o.ChecksumZero(b)
+
+
+def test_fixture_list_is_complete():
+    """tests/golden/make_fixtures.py names every committed fixture (and only those)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_fixtures", os.path.join(ROOT, "tests", "golden", "make_fixtures.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    m.check()
