@@ -117,6 +117,7 @@ int lz4hip_init(int device) {
 }
 
 int lz4hip_shutdown(void) {
+    Stager::release_all();  // pinned staging buffers of the host-pointer entry points
     int n = 0;
     HIPCHK(hipGetDeviceCount(&n));
     for (int d = 0; d < n; d++) {

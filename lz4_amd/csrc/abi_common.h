@@ -97,6 +97,145 @@ struct SideStream {
     }
 };
 
+// Large copies between the caller's (pageable) memory and the device go through two pinned
+// buffers that a few host threads fill or drain while the other one is on the bus: on the
+// MI355X box hipMemcpy from pageable memory runs at 29 GB/s up and 17.5 GB/s down, the staged
+// copy at 50-55 GB/s either way (tools/micro/xfer.hip, profiles/r2_host_xfer.txt).  A Stager
+// belongs to one call at a time (Stager::Lease takes one from a per-device free list) and
+// keeps its 2 x 32 MiB for the next call.
+class Stager {
+public:
+    static constexpr size_t kPiece = 32u << 20, kDirect = 4u << 20;
+    static constexpr int kThreads = 4;
+
+    // Queues h[0,n) -> d on st.  Returns once h has been read; the last pieces may still be
+    // on the bus (work queued on st afterwards is ordered behind them).
+    hipError_t up(void *d, const void *h, size_t n, hipStream_t st) {
+        if (n <= kDirect) return n ? hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, st) : hipSuccess;
+        hipError_t e = ready();
+        int k = 0;
+        for (size_t a = 0; a < n && e == hipSuccess; a += kPiece, k ^= 1) {
+            const size_t m = std::min(kPiece, n - a);
+            if ((e = hipEventSynchronize(ev_[k])) != hipSuccess) break;  // its last copy has left
+            spread(pin_[k], static_cast<const uint8_t *>(h) + a, m);
+            if ((e = hipMemcpyAsync(static_cast<uint8_t *>(d) + a, pin_[k], m, hipMemcpyHostToDevice, st)) != hipSuccess) break;
+            e = hipEventRecord(ev_[k], st);
+        }
+        return e;
+    }
+    // d[0,n) -> h on st, complete on return; arrived(upto) is called as h[0,upto) becomes final.
+    template <class F> hipError_t down(void *h, const void *d, size_t n, hipStream_t st, F &&arrived) {
+        hipError_t e = hipSuccess;
+        if (n <= kDirect) {
+            if (n) e = hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e == hipSuccess && n) arrived(n);
+            return e;
+        }
+        if ((e = ready()) != hipSuccess) return e;
+        size_t at[2] = {0, 0}, len[2] = {0, 0};
+        int k = 0;
+        for (size_t a = 0; a < n + kPiece && e == hipSuccess; a += kPiece, k ^= 1) {
+            if (len[k]) {  // the piece fetched into this buffer two turns ago
+                if ((e = hipEventSynchronize(ev_[k])) != hipSuccess) break;
+                spread(static_cast<uint8_t *>(h) + at[k], pin_[k], len[k]);
+                arrived(at[k] + len[k]);
+                len[k] = 0;
+            }
+            if (a < n) {
+                const size_t m = std::min(kPiece, n - a);
+                if ((e = hipMemcpyAsync(pin_[k], static_cast<const uint8_t *>(d) + a, m, hipMemcpyDeviceToHost, st)) != hipSuccess) break;
+                e = hipEventRecord(ev_[k], st);
+                at[k] = a, len[k] = m;
+            }
+        }
+        if (e == hipSuccess && len[k]) {  // an even count of pieces leaves the last one here
+            if ((e = hipEventSynchronize(ev_[k])) == hipSuccess) {
+                spread(static_cast<uint8_t *>(h) + at[k], pin_[k], len[k]);
+                arrived(at[k] + len[k]);
+            }
+        }
+        if (e != hipSuccess) (void)hipStreamSynchronize(st);  // nothing may land in pin_ after the lease ends
+        return e;
+    }
+    hipError_t down(void *h, const void *d, size_t n, hipStream_t st) {
+        return down(h, d, n, st, [](size_t) {});
+    }
+
+    // One Stager for the duration of a call, from the free list of the current device.
+    class Lease {
+    public:
+        Lease() {
+            if (hipGetDevice(&dev_) != hipSuccess) dev_ = 0;
+            std::lock_guard<std::mutex> g(mu());
+            auto &v = idle()[dev_ & 63];
+            if (!v.empty()) {
+                s_ = v.back();
+                v.pop_back();
+            }
+            if (!s_) s_ = new Stager();
+        }
+        ~Lease() {
+            std::lock_guard<std::mutex> g(mu());
+            idle()[dev_ & 63].push_back(s_);
+        }
+        Stager *operator->() { return s_; }
+
+    private:
+        Stager *s_ = nullptr;
+        int dev_ = 0;
+    };
+    // lz4hip_shutdown(): waits for and releases every idle stager of every device.
+    static void release_all() {
+        std::lock_guard<std::mutex> g(mu());
+        for (int i = 0; i < 64; i++) {
+            auto &v = idle()[i];
+            for (Stager *s : v) delete s;
+            v.clear();
+        }
+    }
+    ~Stager() {
+        for (int i = 0; i < 2; i++) {
+            if (ev_[i]) {
+                (void)hipEventSynchronize(ev_[i]);
+                (void)hipEventDestroy(ev_[i]);
+            }
+            if (pin_[i]) (void)hipHostFree(pin_[i]);
+        }
+    }
+
+private:
+    static std::mutex &mu() {
+        static std::mutex m;
+        return m;
+    }
+    static std::vector<Stager *> *idle() {
+        static std::vector<Stager *> v[64];
+        return v;
+    }
+    hipError_t ready() {
+        for (int i = 0; i < 2; i++) {
+            hipError_t e;
+            if (!pin_[i] && (e = hipHostMalloc((void **)&pin_[i], kPiece, hipHostMallocPortable)) != hipSuccess) return e;
+            if (!ev_[i] && (e = hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming)) != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    static void spread(uint8_t *d, const uint8_t *s, size_t n) {  // memcpy on kThreads threads
+        const size_t per = ((n / kThreads) + 4095) & ~(size_t)4095;
+        std::thread t[kThreads];
+        int used = 0;
+        for (int i = 1; i < kThreads && (size_t)i * per < n; i++, used++) {
+            const size_t a = (size_t)i * per, m = std::min(per, n - a);
+            t[i] = std::thread([=] { memcpy(d + a, s + a, m); });
+        }
+        memcpy(d, s, std::min(per, n));
+        for (int i = 1; i <= used; i++) t[i].join();
+    }
+    uint8_t *pin_[2] = {nullptr, nullptr};
+    hipEvent_t ev_[2] = {nullptr, nullptr};
+};
+
 // ---------------------------------------------------------------------------------
 // XXHZero on the host: internal/xxh32/xxh32zero.go:22-139 restated, Sum32's
 // `uint32(totalLen) >= 16` included (:113-118, SURVEY trap T6).  Product code: the

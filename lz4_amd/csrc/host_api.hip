@@ -14,8 +14,6 @@ using namespace lz4hip;
 
 namespace {
 
-constexpr size_t kCopyPiece = 64u << 20;  // D2H piece after which the hash follower is fed
-
 inline uint32_t rd32(const uint8_t *p) {
     uint32_t v;
     memcpy(&v, p, 4);
@@ -52,7 +50,10 @@ size_t batch_ws_bytes(uint32_t level, size_t nb_data) {
 int compress_batch(const CompressBufs &B, const uint8_t *src, const BatchShape &S,
                    uint64_t first_off, uint64_t frame_base, hipStream_t st, uint64_t *end_off,
                    uint32_t *sw_out) {
-    if (S.n) HIPCHK(hipMemcpyAsync(B.src, src, S.n, hipMemcpyHostToDevice, st));
+    if (S.n) {
+        Stager::Lease stage;
+        HIPCHK(stage->up(B.src, src, S.n, st));
+    }
     HIPCHK(hipMemsetAsync(B.res, 0, (S.nb + 1) * sizeof(int32_t), st));
     // dst_len of every block: len(src) in a standard frame, cap(data) = 8 MiB in a legacy one
     const int dmode = S.legacy ? kDstExplicit : LZ4HIP_DST_FRAME;
@@ -243,8 +244,10 @@ static int64_t frame_compress(const uint8_t *src, size_t n, uint32_t block_size,
     if (rc != LZ4HIP_OK) return rc;
     if (end_off > dst_cap) return fail(LZ4HIP_ERR_SHORT, "frame larger than dst_cap");
     memcpy(dst, hdr, hlen);
-    if (end_off > hlen)
-        HIPCHK(hcopy(dst + hlen, B.frame + hlen, end_off - hlen, hipMemcpyDeviceToHost));
+    if (end_off > hlen) {
+        Stager::Lease stage;
+        HIPCHK(stage->down(dst + hlen, B.frame + hlen, end_off - hlen, kHostStream));
+    }
     size_t tlen;
     if (legacy) {  // no end mark (frame.go:63-65); ReadFrom's empty block: size 1, token 00
         tlen = 0;
@@ -336,7 +339,8 @@ static int64_t legacy_uncompress(const uint8_t *src, size_t n, size_t si, uint8_
                 HIPCHK(d_off.alloc(kLegacyChunk * 8));
                 HIPCHK(d_sw.alloc(kLegacyChunk * 4));
                 HIPCHK(d_len.alloc(kLegacyChunk * 4));
-                HIPCHK(hcopy(d_src.p, src, n, hipMemcpyHostToDevice));
+                Stager::Lease stage;
+                HIPCHK(stage->up(d_src.p, src, n, kHostStream));
                 uploaded = true;
             }
             if (!d_out.p) {
@@ -466,7 +470,8 @@ static int64_t frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size
     HIPCHK(d_xxh.alloc(chunk * 4));
     HIPCHK(d_foff.alloc(chunk * 8));
     if (independent) HIPCHK(d_slots.alloc(chunk * (size_t)bs));
-    HIPCHK(hcopy(d_src.p, src, n, hipMemcpyHostToDevice));
+    Stager::Lease stage;
+    HIPCHK(stage->up(d_src.p, src, n, kHostStream));
     HIPCHK(hcopy(d_off.p, off.data(), nb * 8, hipMemcpyHostToDevice));
     HIPCHK(hcopy(d_sw.p, sw.data(), nb * 4, hipMemcpyHostToDevice));
     std::vector<int32_t> len(chunk);
@@ -518,11 +523,13 @@ static int64_t frame_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size
                                       d_foff.as<uint64_t>(), c, d_flat.as<uint8_t>(), kHostStream));
         }
         // this chunk's bytes go down in pieces; the hash follows each piece
-        while (down < total) {
-            const size_t piece = std::min(kCopyPiece, total - down);
-            HIPCHK(hcopy(dst + down, d_flat.as<uint8_t>() + down, piece, hipMemcpyDeviceToHost));
-            down += piece;
-            if (hasher) hasher->publish(down);
+        if (down < total) {
+            const size_t base = down;
+            HIPCHK(stage->down(dst + base, d_flat.as<uint8_t>() + base, total - base, kHostStream,
+                               [&](size_t upto) {
+                                   if (hasher) hasher->publish(base + upto);
+                               }));
+            down = total;
         }
     }
     if (index_rc != LZ4HIP_OK) return fail(index_rc, index_msg);
@@ -798,8 +805,8 @@ int64_t lz4hip_stream_compress_blocks(lz4hip_stream *s, const uint8_t *src, size
     if (rc != LZ4HIP_OK) return rc;
     if (end_off > dst_cap) return fail(LZ4HIP_ERR_SHORT, "dst_cap too small");
     if (end_off) {
-        HIPCHK(hipMemcpyAsync(dst, s->W.frame, end_off, hipMemcpyDeviceToHost, s->st));
-        HIPCHK(hipStreamSynchronize(s->st));
+        Stager::Lease stage;
+        HIPCHK(stage->down(dst, s->W.frame, end_off, s->st));
     }
     if (block_lens)
         for (size_t b = 0; b < S.nb; b++) block_lens[b] &= 0x7FFFFFFFu;
@@ -848,7 +855,8 @@ int64_t lz4hip_stream_uncompress_blocks(lz4hip_stream *s, const uint8_t *src, si
         DeviceGuard g;
         HIPCHK(g.enter(s->device));
         hipStream_t st = s->st;
-        HIPCHK(hipMemcpyAsync(s->r_src, src, si, hipMemcpyHostToDevice, st));
+        Stager::Lease stage;
+        HIPCHK(stage->up(s->r_src, src, si, st));
         HIPCHK(hipMemcpyAsync(s->r_off, off.data(), nb * 8, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(s->r_sw, sw.data(), nb * 4, hipMemcpyHostToDevice, st));
         HIPCHK(launch_decode(s->r_src, si, s->r_off, s->r_sw, nb, s->r_slots, bs, bs, 0, nullptr,
@@ -874,13 +882,9 @@ int64_t lz4hip_stream_uncompress_blocks(lz4hip_stream *s, const uint8_t *src, si
         HIPCHK(launch_pack_blocks(s->r_slots, bs, s->r_len, s->r_foff, nb, s->r_flat, st));
         std::unique_ptr<HashFollower> hasher;
         if (csum) hasher.reset(new HashFollower(&s->xxh, dst));  // the collector's Write: :173-176
-        for (size_t down = 0; down < (size_t)total;) {
-            const size_t piece = std::min(kCopyPiece, (size_t)total - down);
-            HIPCHK(hipMemcpyAsync(dst + down, s->r_flat + down, piece, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            down += piece;
-            if (hasher) hasher->publish(down);
-        }
+        HIPCHK(stage->down(dst, s->r_flat, (size_t)total, st, [&](size_t upto) {
+            if (hasher) hasher->publish(upto);
+        }));
     }
     *consumed = si;
     if (n_blocks) *n_blocks = nb;

@@ -487,3 +487,29 @@ def test_uncompress_blocks_rejects_spans_outside_src(oracle):
         ol = ol.cpu().numpy()
         assert list(ol[:3]) == [900, 900, 900] and list(ol[3:]) == [-1, -1, -1]
         assert out[0, :900].cpu().numpy().tobytes() == b"inside the buffer " * 50
+
+
+# ---------------------------------------------------------------- staged host copies
+
+@pytest.mark.parametrize("mib", [5, 33, 64, 70])
+def test_host_frames_through_staged_copies(oracle, mib):
+    """Host buffers above 4 MiB travel through two 32 MiB pinned buffers (abi_common.h Stager):
+    one piece, one and a bit, exactly two, three -- frame bytes equal the oracle's Writer
+    (content + block checksums), and the frame reads back through the same staging."""
+    from lz4_amd import _lib, corpus
+    n = mib << 20
+    data = corpus.generate("mixed", 11 + mib, n)
+    flags = _lib.F_CONTENT_CHECKSUM | _lib.F_BLOCK_CHECKSUM
+    frame = frame_compress(data, 1 << 18, flags)
+    assert frame == oracle.frame_compress(data, 1 << 18, flags)
+    k, back = frame_uncompress(frame, n)
+    assert k == n and back == data.tobytes()
+    # a Stream handle takes the same path: one batch of the whole input
+    s = Stream(1 << 18, flags, 0, n >> 18)
+    try:
+        entries, _ = s.compress(data)
+        assert entries == frame[7:7 + len(entries)] and len(entries) == len(frame) - 7 - 8
+        k, back, used, end, _ = s.uncompress(entries, n)
+        assert k == n and back == data.tobytes() and used == len(entries) and end == 0
+    finally:
+        s.close()
