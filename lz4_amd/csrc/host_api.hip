@@ -36,9 +36,30 @@ struct BatchShape {
     bool legacy, bsum;
 };
 
+// A large Fast batch is compressed in sub-batches of kPipeBytes while the rest of the source
+// is still on its way up: sub-batch j's kernel waits only for its own bytes and runs on one
+// of kPipeStreams side streams with a third of the tables, so that up to three of them fill
+// the chip together.  0 = this batch is not pipelined.
+constexpr size_t kPipeBytes = 256u << 20, kPipeSlots = 1024, kPipePart = kPipeSlots * kFastSlotBytes + kFastCounterBytes;
+constexpr int kPipeStreams = 3;
+
+size_t pipe_blocks(uint32_t level, bool legacy, uint32_t bs, size_t nb_data, size_t ws_bytes) {
+    const size_t sub = std::max(kPipeSlots, kPipeBytes / bs);
+    return level == 0 && !legacy && nb_data >= kPipeStreams * sub && ws_bytes >= kPipeStreams * kPipePart ? sub : 0;
+}
+
+struct Event {
+    hipEvent_t e = nullptr;
+    hipError_t create() { return hipEventCreateWithFlags(&e, hipEventDisableTiming); }
+    ~Event() {
+        if (e) (void)hipEventDestroy(e);
+    }
+};
+
 size_t batch_ws_bytes(uint32_t level, size_t nb_data) {
     if (!nb_data) return 0;
-    if (level == 0) return lz4hip_fast_workspace_bytes(nb_data);
+    if (level == 0)  // + the block counters of the pipelined sub-batches' own table ranges
+        return lz4hip_fast_workspace_bytes(nb_data) + kPipeStreams * kFastCounterBytes;
     return (nb_data < kHcSlots ? nb_data : kHcSlots) * kHcSlotBytes + kFastCounterBytes;
 }
 
@@ -47,17 +68,48 @@ size_t batch_ws_bytes(uint32_t level, size_t nb_data) {
 // first_off and writes the entries "u32 size | data | [u32 checksum]" to B.frame (whose
 // byte 0 is frame offset frame_base).  On return the stream is idle, *end_off is the
 // offset behind the last entry and, if sw_out, the size words are on the host.
+int finish_batch(const CompressBufs &B, const BatchShape &S, uint64_t first_off, uint64_t frame_base,
+                 hipStream_t st, uint64_t *end_off, uint32_t *sw_out);
+
 int compress_batch(const CompressBufs &B, const uint8_t *src, const BatchShape &S,
                    uint64_t first_off, uint64_t frame_base, hipStream_t st, uint64_t *end_off,
                    uint32_t *sw_out) {
-    if (S.n) {
-        Stager::Lease stage;
-        HIPCHK(stage->up(B.src, src, S.n, st));
-    }
     HIPCHK(hipMemsetAsync(B.res, 0, (S.nb + 1) * sizeof(int32_t), st));
     // dst_len of every block: len(src) in a standard frame, cap(data) = 8 MiB in a legacy one
     const int dmode = S.legacy ? kDstExplicit : LZ4HIP_DST_FRAME;
     const uint32_t dlen_x = S.legacy ? kLegacyBlock : 0;
+    Stager::Lease stage;
+    const size_t sub = pipe_blocks(S.level, S.legacy, S.bs, S.nb_data, B.ws_bytes);
+    if (sub) {
+        // declared after the caller's buffers: the side streams are drained before those die
+        SideStream side[kPipeStreams];
+        Event up[kPipeStreams], done[kPipeStreams];
+        for (int p = 0; p < kPipeStreams; p++) {
+            HIPCHK(side[p].create());
+            HIPCHK(up[p].create());
+            HIPCHK(done[p].create());
+        }
+        size_t j = 0;
+        for (size_t b0 = 0; b0 < S.nb_data; b0 += sub, j++) {
+            const int p = (int)(j % kPipeStreams);
+            const size_t c = std::min(sub, S.nb_data - b0), o = b0 * S.bs, len = std::min(c * S.bs, S.n - o);
+            HIPCHK(stage->up(B.src + o, src + o, len, st));
+            HIPCHK(hipEventRecord(up[p].e, st));
+            HIPCHK(hipStreamWaitEvent(side[p].s, up[p].e, 0));
+            uint8_t *w = static_cast<uint8_t *>(B.ws) + (size_t)p * kPipePart;
+            size_t slots = 0;
+            uint32_t *next_block = fast_ws_split(w, kPipePart, slots);
+            HIPCHK(launch_fast(B.src + o, len, S.bs, c, dmode, dlen_x, B.comp + o, S.bs, B.res + b0,
+                               (uint16_t *)w, slots, next_block, side[p].s));
+        }
+        for (int p = 0; p < kPipeStreams; p++) {
+            HIPCHK(hipEventRecord(done[p].e, side[p].s));
+            HIPCHK(hipStreamWaitEvent(st, done[p].e, 0));
+        }
+        // finish_batch leaves st idle, and with it the side streams it waits for
+        return finish_batch(B, S, first_off, frame_base, st, end_off, sw_out);
+    }
+    if (S.n) HIPCHK(stage->up(B.src, src, S.n, st));
     if (S.nb_data) {
         if (S.level == 0) {
             size_t slots = 0;
@@ -76,6 +128,13 @@ int compress_batch(const CompressBufs &B, const uint8_t *src, const BatchShape &
                              B.res, (uint32_t *)B.ws, slots, next_block, st));
         }
     }
+    return finish_batch(B, S, first_off, frame_base, st, end_off, sw_out);
+}
+
+// The per-block tail of a batch once every block is compressed: block checksums, the scan of
+// the entry offsets, the entries written into the frame; leaves st idle.
+int finish_batch(const CompressBufs &B, const BatchShape &S, uint64_t first_off, uint64_t frame_base,
+                 hipStream_t st, uint64_t *end_off, uint32_t *sw_out) {
     if (S.bsum)  // over the UNCOMPRESSED bytes: lz4stream/block.go:248-250
         HIPCHK(launch_xxh32_blocks(B.src, S.n, S.bs, nullptr, nullptr, S.nb, B.xxh, st));
     HIPCHK(launch_frame_layout(B.res, S.n, S.bs, S.nb, S.bsum ? B.xxh : nullptr, first_off, B.off,

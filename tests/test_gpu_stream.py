@@ -513,3 +513,41 @@ def test_host_frames_through_staged_copies(oracle, mib):
         assert k == n and back == data.tobytes() and used == len(entries) and end == 0
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("bs,mib", [(1 << 18, 800), (1 << 16, 769)])
+def test_host_frame_compress_pipelined_sub_batches(oracle, bs, mib):
+    """From 768 MiB up (256 KiB blocks and smaller) lz4hip_frame_compress compresses sub-batches
+    of 256 MiB on side streams while the rest of the source is still being uploaded
+    (host_api.hip compress_batch).  The frame equals the single-launch device path block for
+    block -- entry bytes from lz4hip_compress_fast_blocks + frame_layout/scatter -- a sample
+    of blocks equals the oracle's, and the frame reads back to the source with both
+    checksums verified."""
+    import torch as T
+    from lz4_amd import _lib, corpus, device as dev
+    n = (mib << 20) + 12345
+    data = corpus.generate("mixed", 77, n)
+    flags = _lib.F_CONTENT_CHECKSUM | _lib.F_BLOCK_CHECKSUM
+    frame = frame_compress(data, bs, flags)
+    nb = -(-n // bs)
+    # the same blocks in one launch on the device path
+    src = T.from_numpy(data).to("cuda:0")
+    comp, res = dev.compress_blocks(src, bs, 0)
+    xxh = dev.xxh32_blocks(src, bs, nb, n=n)
+    off, sw = dev.frame_layout(res, n, bs, nb, xxh, 7)
+    end = int(off[nb].item())
+    body = T.empty(end + 16, dtype=T.uint8, device=src.device)
+    dev.frame_scatter(src, bs, comp, res, off, nb, body, 0, xxh, n=n)
+    assert len(frame) == end + 8
+    assert frame[7:end] == body[7:end].cpu().numpy().tobytes()
+    off_h = off.cpu().numpy()
+    for b in (0, 1023, 1024, 2047, 2048, nb // 2, nb - 2, nb - 1):
+        blk = data[b * bs:min(n, (b + 1) * bs)]
+        _, osw, oxx = oracle.compress_blocks(blk, bs, 0, 1, True)
+        at = int(off_h[b])
+        assert struct.unpack_from("<I", frame, at)[0] == osw[0], b
+        size = int(osw[0] & 0x7FFFFFFF)
+        assert struct.unpack_from("<I", frame, at + 4 + size)[0] == oxx[0], b
+    del src, comp, body
+    k, back = frame_uncompress(frame, n)
+    assert k == n and back == data.tobytes()
