@@ -17,7 +17,8 @@ After the timed region the same run exercises the cfg5 FRAME path through
 lz4_amd.shard (Writer: compress + span gather to rank 0 + assembly; Reader: index,
 span scatter, decode, verification), with and without the content checksum, on
 `--frame-gib` GiB per GPU of the mixed corpus in 4 MiB blocks, and reports it under
-"frame_path" (extra keys; the headline metric does not include it).
+"frame_path" (extra keys; the headline metric does not include it).  A watchdog prints the
+headline without that section if it does not finish within `--frame-timeout` seconds.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--size-gib G]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -47,7 +48,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size-gib", type=float, default=8.0, help="GiB per corpus per GPU")
-    ap.add_argument("--frame-gib", type=float, default=2.0,
+    ap.add_argument("--frame-timeout", type=int, default=180,
+                    help="seconds after which the headline is printed without the frame-path section")
+    ap.add_argument("--frame-gib", type=float, default=8.0,
                     help="GiB per GPU for the cfg5 frame path after the timed region (0: skip)")
     ap.add_argument("--cpu-sample-mib", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -206,55 +209,7 @@ def main():
                    "compress_GBps": round(m * reps / tc / 1e9, 3),
                    "decompress_GBps": round(m * reps / td / 1e9, 3)}
 
-    # ---- cfg5 frame path through lz4_amd.shard (outside the headline's timed region) ----
-    frame_path = None
-    if args.frame_gib > 0:
-        try:
-            from lz4_amd import shard
-            BS_F = 1 << 22
-            share = min(int(args.frame_gib * (1 << 30)), n) // BS_F * BS_F
-            src_f = mixed[:share]               # this rank's block range of the stream
-            n_total = share * world
-            del comp, out
-            torch.cuda.empty_cache()
-            fp = {"write_GBps": {}, "read_GBps": {}, "phases_s": {}}
-            ok_rt = True
-            for label, flags in (("no_content_checksum", 1), ("content_checksum", 3)):
-                ws, rs = {}, {}
-                shard.frame_compress_sharded(src_f[:BS_F], BS_F * world, BS_F, flags, 0)   # warm-up
-                barrier()
-                t0 = time.perf_counter()
-                frame = shard.frame_compress_sharded(src_f, n_total, BS_F, flags, 0, stats=ws)
-                barrier()
-                t1 = time.perf_counter()
-                flat, _, tot = shard.frame_uncompress_sharded(frame, frame.numel() if rank == 0 else 0, stats=rs)
-                barrier()
-                t2 = time.perf_counter()
-                ok_rt &= tot == n_total and torch.equal(flat, src_f)
-                fp["write_GBps"][label] = round(n_total / (t1 - t0) / 1e9, 3)
-                fp["read_GBps"][label] = round(n_total / (t2 - t1) / 1e9, 3)
-                fp["phases_s"][label] = {"write": {k: round(v, 4) for k, v in ws.items() if k.endswith("_s")},
-                                         "read": {k: round(v, 4) for k, v in rs.items() if k.endswith("_s")}}
-                if rank == 0 and flags == 1:
-                    gb = ws.get("gather_bytes", 0)
-                    peak = 153.0 * min(world - 1, 7)
-                    fp["gather"] = {"bytes": gb, "seconds": round(ws.get("gather_s", 0.0), 4),
-                                    "GBps": round(gb / max(ws.get("gather_s", 0.0), 1e-9) / 1e9, 2) if gb else 0.0,
-                                    "peak_GBps": peak,
-                                    "note": "spans received straight into the frame, one xGMI link per sender "
-                                            "(7 x 153 GB/s inbound at the root)"}
-                    fp["frame_bytes"] = int(frame.numel())
-                del frame, flat
-            flag = torch.tensor([1 if ok_rt else 0], dtype=torch.int64, device="cpu" if one_dev else device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            fp["round_trip_equals_source"] = bool(flag.item())
-            fp["workload"] = ("cfg5 share: %.2f GiB/GPU of the mixed corpus, 4MB blocks, xxh32 block checksums, "
-                              "Writer + Reader through lz4_amd.shard; content checksum chain on the host"
-                              % (share / 2**30))
-            frame_path = fp
-        except Exception as e:  # the headline line must survive a failure of this extra section
-            frame_path = {"error": "%s: %s" % (type(e).__name__, e)}
-
+    line = None
     if rank == 0:
         total = args.steps * 2 * n * world
         alg_bytes = n + c_mixed + 8 * nb_c  # N read + C written + 8 B/block
@@ -306,10 +261,85 @@ def main():
                          "decode_frac": round((n + c_text) / t_dec / 1e9 / HBM_PEAK_GBPS, 5)},
             "cpu_baseline": cpu,
             "parity": parity,
-            "frame_path": frame_path,
         }
-        print(json.dumps(line), flush=True)
+
+    # The line is complete but for the extra frame-path section.  That section is the only
+    # part of this program with rank-to-rank transfers; a watchdog prints the headline
+    # without it and ends the process if it (or the closing barrier) does not come back, so a
+    # stuck transfer cannot take the measured line with it.
+    import threading
+    emit_lock = threading.Lock()
+    emitted = [False]
+
+    def emit(fp):
+        with emit_lock:
+            if emitted[0] or line is None:
+                return
+            emitted[0] = True
+            line["frame_path"] = fp
+            print(json.dumps(line), flush=True)
+
+    def bail():
+        emit({"error": "the frame path did not finish within %d s" % args.frame_timeout})
+        sys.stdout.flush()
+        os._exit(0)
+
+    guard = threading.Timer(args.frame_timeout, bail)
+    guard.daemon = True
+    guard.start()
+
+    # ---- cfg5 frame path through lz4_amd.shard (outside the headline's timed region) ----
+    frame_path = None
+    if args.frame_gib > 0:
+        try:
+            from lz4_amd import shard
+            BS_F = 1 << 22
+            share = min(int(args.frame_gib * (1 << 30)), n) // BS_F * BS_F
+            src_f = mixed[:share]               # this rank's block range of the stream
+            n_total = share * world
+            del comp, out
+            torch.cuda.empty_cache()
+            fp = {"write_GBps": {}, "read_GBps": {}, "phases_s": {}}
+            ok_rt = True
+            for label, flags in (("no_content_checksum", 1), ("content_checksum", 3)):
+                ws, rs = {}, {}
+                shard.frame_compress_sharded(src_f[:BS_F], BS_F * world, BS_F, flags, 0)   # warm-up
+                barrier()
+                t0 = time.perf_counter()
+                frame = shard.frame_compress_sharded(src_f, n_total, BS_F, flags, 0, stats=ws)
+                barrier()
+                t1 = time.perf_counter()
+                flat, _, tot = shard.frame_uncompress_sharded(frame, frame.numel() if rank == 0 else 0, stats=rs)
+                barrier()
+                t2 = time.perf_counter()
+                ok_rt &= tot == n_total and torch.equal(flat, src_f)
+                fp["write_GBps"][label] = round(n_total / (t1 - t0) / 1e9, 3)
+                fp["read_GBps"][label] = round(n_total / (t2 - t1) / 1e9, 3)
+                fp["phases_s"][label] = {"write": {k: round(v, 4) for k, v in ws.items() if k.endswith("_s")},
+                                         "read": {k: round(v, 4) for k, v in rs.items() if k.endswith("_s")}}
+                if rank == 0 and flags == 1:
+                    gb = ws.get("gather_bytes", 0)
+                    peak = 153.0 * min(world - 1, 7)
+                    fp["gather"] = {"bytes": gb, "seconds": round(ws.get("gather_s", 0.0), 4),
+                                    "GBps": round(gb / max(ws.get("gather_s", 0.0), 1e-9) / 1e9, 2) if gb else 0.0,
+                                    "peak_GBps": peak,
+                                    "note": "spans received straight into the frame, one xGMI link per sender "
+                                            "(7 x 153 GB/s inbound at the root)"}
+                    fp["frame_bytes"] = int(frame.numel())
+                del frame, flat
+            flag = torch.tensor([1 if ok_rt else 0], dtype=torch.int64, device="cpu" if one_dev else device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            fp["round_trip_equals_source"] = bool(flag.item())
+            fp["workload"] = ("cfg5 share: %.2f GiB/GPU of the mixed corpus, 4MB blocks, xxh32 block checksums, "
+                              "Writer + Reader through lz4_amd.shard; content checksum chain on the host"
+                              % (share / 2**30))
+            frame_path = fp
+        except Exception as e:  # the headline line must survive a failure of this extra section
+            frame_path = {"error": "%s: %s" % (type(e).__name__, e)}
+    emit(frame_path)
+
     dist.barrier()
+    guard.cancel()
     dist.destroy_process_group()
 
 
