@@ -28,6 +28,8 @@ read (Reader, reader.go:81-196; lz4stream/block.go:95-194)
 Compute is the device path of device.py; `ops` is injectable so that the exchange logic
 can be rehearsed on CPU with gloo (tests/test_shard_gloo.py).
 """
+import threading
+
 import torch
 import torch.distributed as dist
 
@@ -171,6 +173,42 @@ class _Wire:
         return int(dg.item()) & 0xFFFFFFFF
 
 
+class _HashAhead(threading.Thread):
+    """The head of the content-checksum chain.  The first rank needs no state from anyone, so
+    its share is hashed from the start of the call, beside its own compression (on the product
+    path: a side stream brings the bytes down, a host core steps the chain, the GIL is free
+    during the call)."""
+
+    def __init__(self, ops, src, n, final):
+        super().__init__(daemon=True)
+        self.ops, self.src, self.n, self.final = ops, src, n, final
+        self.state = torch.zeros(6, dtype=torch.int32)
+        self.digest, self.err, self.side = None, None, None
+        if src.is_cuda:
+            self.side = torch.cuda.Stream(device=src.device)
+            self.side.wait_stream(torch.cuda.current_stream(src.device))   # src is complete there
+        self.start()
+
+    def run(self):
+        try:
+            if self.side is not None:
+                torch.cuda.set_device(self.src.device)
+                with torch.cuda.stream(self.side):
+                    self.digest = self.ops.xxh32_update(self.src, self.n, self.state, True, self.final)
+                    self.side.synchronize()
+            else:
+                self.digest = self.ops.xxh32_update(self.src, self.n, self.state, True, self.final)
+        except BaseException as e:   # handed to the caller's thread by result()
+            self.err = e
+
+    def result(self, state):
+        self.join()
+        if self.err is not None:
+            raise self.err
+        state.copy_(self.state)
+        return self.digest
+
+
 class _Clock:
     """Phase timer for bench.py: stats[name] += seconds between marks.  Synchronises the
     device at every mark, so it is only used when a caller asks for stats."""
@@ -216,6 +254,7 @@ def frame_compress_sharded(src_local, n_total, block_size, flags=_lib.F_CONTENT_
     nb = (hi - lo) + extra
     bsum, csum = bool(flags & _lib.F_BLOCK_CHECKSUM), bool(flags & _lib.F_CONTENT_CHECKSUM)
 
+    ahead = _HashAhead(ops, src_local, n_local, last) if csum and rank == 0 else None
     result = torch.zeros(nb + 1, dtype=torch.int32, device=dev)
     comp = None
     if hi > lo:
@@ -265,7 +304,8 @@ def frame_compress_sharded(src_local, n_total, block_size, flags=_lib.F_CONTENT_
     if csum:
         state = torch.zeros(6, dtype=torch.int32)
         dg = wire.relay_state(state, 0, world - 1,
-                              lambda st: ops.xxh32_update(src_local, n_local, st, rank == 0, last))
+                              lambda st: ahead.result(st) if ahead is not None else
+                              ops.xxh32_update(src_local, n_local, st, False, last))
         if rank == root:
             at = total - 4
             frame[at:at + 4] = torch.tensor([dg & 0xFF, dg >> 8 & 0xFF, dg >> 16 & 0xFF, dg >> 24],
