@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's kernel measurements on one GPU box, torch-free (tools/prof/prof_bench over the
 # C ABI): timings, rocprofv3 kernel stats and PMC passes at the bench size, per dispatch.
-#   tools/prof/profile.sh TAG [fast|decode|hc|all]      results under gpurun_out/TAG/
+#   tools/prof/profile.sh TAG [fast|decode|hc|lds|all]      results under gpurun_out/TAG/
 TAG=$1; WHAT=${2:-all}
 R=$PWD
 O=$R/gpurun_out/$TAG
@@ -52,6 +52,17 @@ if [ $WHAT = all ] || [ $WHAT = hc ]; then
   pmc hc_mem "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" binary 1 20 hc 1 131072 || exit 1
   pmc hc_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" binary 1 20 hc 1 131072 || exit 1
   for p in hc_mem hc_sq; do echo "# pass $p: prof_bench binary 1 GiB, 1 MiB blocks, HC depth 131072, 1 rep"; python3 $R/tools/prof/pmc_rows.py $O/pmc_$p $N; done > $O/pmc_hc_rows.txt
+fi
+if [ $WHAT = all ] || [ $WHAT = lds ]; then
+  # LDS bank conflicts and wave occupancy of the three kernels (north star: "rocprof counters for ... LDS bank
+  # conflicts and wave occupancy"); resident waves per CU = SQ_WAVE_CYCLES / SQ_BUSY_CU_CYCLES
+  L="SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES"
+  pmc lds_fast "$L" mixed 8 18 fast 1 || exit 1
+  pmc lds_decode "$L" text 8 16 decode 1 || exit 1
+  pmc lds_hc "$L" binary 1 20 hc 1 131072 || exit 1
+  { echo "# pass lds_fast: prof_bench mixed 8 GiB, 256 KiB blocks, Fast, 1 rep"; python3 $R/tools/prof/pmc_rows.py $O/pmc_lds_fast $((8<<30))
+    echo "# pass lds_decode: prof_bench text 8 GiB, 64 KiB blocks, decode, 1 rep"; python3 $R/tools/prof/pmc_rows.py $O/pmc_lds_decode $((8<<30))
+    echo "# pass lds_hc: prof_bench binary 1 GiB, 1 MiB blocks, HC depth 131072, 1 rep"; python3 $R/tools/prof/pmc_rows.py $O/pmc_lds_hc $((1<<30)); } > $O/pmc_lds_rows.txt
 fi
 cd $R
 ls $O
