@@ -354,3 +354,19 @@ def test_on_block_done_handlers(oracle):
     zw.Write(raw)
     zw.Close()
     assert seen5 == [len(lw.getvalue()) - 8]
+
+
+@pytest.mark.parametrize("level", [0, 512])
+def test_frame_compress_equals_reference_golden_random(level):
+    """testdata/random.data.lz4 (a reference fixture) is all stored blocks: the HIP Writer path
+    must reproduce it byte for byte -- header, raw size words, end mark, content checksum
+    (lz4stream/block.go:238-276, frame.go:59-74)."""
+    from lz4_amd import _lib
+    lib = _lib.load()
+    src = np.frombuffer(load("random.data"), dtype=np.uint8)
+    cap = lib.lz4hip_frame_bound(src.size, 1 << 16, _lib.F_CONTENT_CHECKSUM)
+    dst = np.zeros(cap, dtype=np.uint8)
+    k = lib.lz4hip_frame_compress(src.ctypes.data, src.size, 1 << 16, _lib.F_CONTENT_CHECKSUM, level, 0,
+                                  dst.ctypes.data, cap)
+    assert k > 0, lib.lz4hip_last_error()
+    assert dst[:k].tobytes() == load("random.data.lz4")

@@ -352,3 +352,15 @@ def test_two_restatements_agree_on_quirk_paths():
     for hc in (3, 64):
         a, b = _both(src, None, hc)
         assert a == b, hc
+
+
+def test_writer_output_pinned_by_reference_golden_random():
+    """The one golden frame of the reference's testdata whose bytes do not depend on whose
+    compressor made it: random.data is incompressible, every 64 KiB block is stored raw
+    (lz4stream/block.go:238-245), so header, size words with the raw bit, end mark and content
+    checksum of the Writer restatement must equal testdata/random.data.lz4 byte for byte.  (The
+    other goldens are C-lz4 output and differ from pierrec's parse -- compressed-byte parity
+    stays unpinned)"""
+    want = load("random.data.lz4")
+    for level in (0, 512):
+        assert o.frame_compress(load("random.data"), 1 << 16, o.F_CONTENT_CHECKSUM, level) == want
