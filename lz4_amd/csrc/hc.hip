@@ -9,7 +9,8 @@
 //   * Chain candidates are collected 64 at a time (one per lane) and their
 //     prefix lengths are computed by the lanes in parallel; a wave max-reduction
 //     resolves to the reference's winner.  The 1-byte gate of :358-360 is a pure
-//     filter on that winner and is not needed.
+//     filter on that winner: it is not needed for the result, and is used
+//     as a shortcut -- one load instead of a long prefix compare -- once a match is held.
 //   * Emission (token, length runs, literal copy) is 64 lanes wide.
 #include "common.h"
 
@@ -25,6 +26,9 @@ namespace lz4hip {
 // fetch per 64 candidates instead of one per candidate, in the same candidate order, and
 // the fetch of the next entry is in flight while the current 64 candidates are compared.
 static_assert(kHcLinks == kWave, "one link per lane");
+#ifndef LZ4HIP_HC_GATE
+#define LZ4HIP_HC_GATE 8  // held match length from which the one-load gate precedes the prefix compare
+#endif
 constexpr int kHcSlotWords = (1 << 16) + (1 << 16) * kHcLinks / 2;
 
 // Links of a position inserted behind `head` (distance d0 > 0, inside the window), given
@@ -242,7 +246,15 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                     uint32_t l_next = 0;
                     if (in_window(next)) l_next = chain_table[(size_t)(next & kWinMask) * kHcLinks + lane];
                     int ml = 0;
-                    if (lane < cnt) ml = hc_prefix_len(s, mine, si, lim);
+                    if (lane < cnt) {
+                        // The reference's gate (:358-360) as a shortcut once a long match is
+                        // held: a candidate replaces the winner only if it is strictly longer,
+                        // so it must agree with si at index m_len -- and a chain's later
+                        // members mostly do not.  One load decides that instead of a compare
+                        // over m_len bytes (several dependent round trips the wave waits for).
+                        const bool gate = m_len < LZ4HIP_HC_GATE || ld64(s + mine + m_len - 7) == ld64(s + si + m_len - 7);
+                        if (gate) ml = hc_prefix_len(s, mine, si, lim);
+                    }
                     // winner: max ml, ties to the earliest chain entry (lowest lane)
                     const int key = ml >= kMinMatch ? (ml << 6) | (63 - lane) : 0;
                     const int best = wave_max(key);
