@@ -107,15 +107,37 @@ __device__ __forceinline__ int wave_max(int v) {
 // finished in order, the wave one link per lane: from its own staged row, or from the twin's
 // FINISHED row (a run of equal bytes resolves at LDS latency, no memory round trip), and each
 // finished row goes out as one 128-byte store.
+//
+// `pre`: the search that follows the match (at pre->pos) rides along with the first round: its
+// 4 bytes, its head and the head's entry are fetched beside the round's own three fetches, so
+// that search starts with everything in registers.  They are what the search itself would
+// read unless a position of the run has its hash (then the run moved that head): ok = false.
+struct HcPre {
+    int pos;     // < 0: none
+    uint64_t w;  // the 8 source bytes at pos
+    uint32_t h, l;
+    int head;
+    bool ok;
+};
+
 __device__ __forceinline__ void hc_insert_run(uint32_t *hash_table, uint16_t *chain_table,
                                               const uint8_t *__restrict__ s, int p0, int n,
-                                              int lane, uint16_t *rows) {
+                                              int lane, uint16_t *rows, HcPre &pre) {
     typedef uint4 __attribute__((may_alias)) uint4_a;
     for (int base = 0; base < n; base += kWave) {
         const int cnt = n - base < kWave ? n - base : kWave;
         const bool act = lane < cnt;
         const int p = p0 + base + lane;
+        const bool ride = base == 0 && pre.pos >= 0;
+        if (ride) pre.w = ld64(s + pre.pos);
         const uint32_t hh = act ? hash4(ld32(s + p)) : 0xFFFFFFFFu;
+        if (ride) {
+            pre.h = hash4((uint32_t)pre.w);
+            pre.head = (int)hash_table[pre.h];
+            pre.l = 0;
+            pre.ok = true;
+        }
+        if (pre.pos >= 0 && ballot(act && hh == pre.h)) pre.ok = false;
         int twin = -1;        // nearest earlier lane with my hash
         bool later = false;   // a later lane has my hash: it, not I, ends up in the table
         for (int i = 0; i < cnt; i++) {
@@ -137,6 +159,8 @@ __device__ __forceinline__ void hc_insert_run(uint32_t *hash_table, uint16_t *ch
                 for (int q = 0; q < kHcLinks / 8; q++) r[q] = e[q];
             }
         }
+        if (ride && pre.head > 0 && pre.pos - pre.head < kWinSize)
+            pre.l = chain_table[(size_t)(pre.head & kWinMask) * kHcLinks + lane];
         __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         for (int i = 0; i < cnt; i++) {
             const int t = __builtin_amdgcn_readlane(twin, i);
@@ -201,14 +225,24 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
         const int sn = n - kMfLimit;
         bool failed = false;
 
+        HcPre pre;
+        pre.pos = -1;
+        pre.ok = false;
+        pre.w = 0;
+        pre.h = pre.l = 0;
+        pre.head = 0;
         while (si < sn) {
-            uint32_t match = ld32(s + si);
-            const uint32_t h = hash4(match);
+            // fetched beside the last match's insertion
+            const bool ridden = pre.ok && pre.pos == si;
+            pre.ok = false;
+            const uint64_t w = ridden ? pre.w : ld64(s + si);
+            uint32_t match = (uint32_t)w;
+            const uint32_t h = ridden ? pre.h : hash4(match);
             int m_len = 0, offset = 0;
             uint32_t my_link = 0;  // lane j: link j of si's own chain entry (from the first batch)
             {
                 const int lim = sn - si;
-                int next = (int)hash_table[h];
+                int next = ridden ? pre.head : (int)hash_table[h];
                 uint32_t tries = depth;
                 // A prefix length never exceeds lim rounded up to 8 (:363-372) and only a
                 // strictly longer candidate replaces the winner (:373), so the walk can
@@ -217,7 +251,7 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                 auto in_window = [&](int q) { return q > 0 && si - q < kWinSize; };
                 // `l`: lane j's link of cur's entry, fetched one batch ahead
                 uint32_t l = 0;
-                if (in_window(next)) l = chain_table[(size_t)(next & kWinMask) * kHcLinks + lane];
+                if (in_window(next)) l = ridden ? pre.l : chain_table[(size_t)(next & kWinMask) * kHcLinks + lane];
                 bool first = true;
                 while (tries > 0 && in_window(next) && m_len < ml_max) {
                     // one batch = cur itself (lane 0) and cur's links 0..62 (lanes 1..63);
@@ -281,8 +315,11 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                 const int wsn = si + m_len - kWinSize;
                 if (wsn > p) p = wsn;
                 const int end = si + m_len;
+                pre.pos = -1;
                 if (wsn <= si + 1) {
-                    hc_insert_run(hash_table, chain_table, s, p, end - p, lane, rows);
+                    if (end < sn) pre.pos = end;
+                    hc_insert_run(hash_table, chain_table, s, p, end - p, lane, rows, pre);
+                    if (pre.h == h) pre.ok = false;  // si itself is then the head
                 } else {
                     // The reference rolls the 4-byte value from the one at si
                     // (:399-400).  When the window clamp skips positions (match
