@@ -120,64 +120,81 @@ struct HcPre {
     bool ok;
 };
 
+// One round: up to 64 positions in increasing order, lane i <-> pos (with its hash hh), not
+// necessarily consecutive.
+__device__ __forceinline__ void hc_insert_round(uint32_t *hash_table, uint16_t *chain_table,
+                                                const uint8_t *__restrict__ s, const int p,
+                                                const uint32_t hh_in, const int cnt, const int lane,
+                                                uint16_t *rows, HcPre &pre, const bool ride) {
+    typedef uint4 __attribute__((may_alias)) uint4_a;
+    const bool act = lane < cnt;
+    const uint32_t hh = act ? hh_in : 0xFFFFFFFFu;
+    if (ride) {
+        pre.h = hash4((uint32_t)pre.w);
+        pre.head = (int)hash_table[pre.h];
+        pre.l = 0;
+        pre.ok = true;
+    }
+    if (pre.pos >= 0 && ballot(act && hh == pre.h)) pre.ok = false;
+    int twin = -1;        // nearest earlier lane with my hash
+    bool later = false;   // a later lane has my hash: it, not I, ends up in the table
+    for (int i = 0; i < cnt; i++) {
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)hh, i);
+        if (act && hh == hi) {
+            if (lane > i) twin = i;
+            if (lane < i) later = true;
+        }
+    }
+    // distance to the position I link to: the twin, or the table's head (0: none, or out of
+    // the window -- the reference's walk stops there, :355)
+    int d0 = 0;
+    const int twin_pos = __shfl(p, twin < 0 ? lane : twin);  // every lane takes part in the shuffle
+    if (twin >= 0) {
+        d0 = p - twin_pos;
+        if (d0 >= kWinSize) d0 = 0;
+    }
+    if (act && twin < 0) {
+        const int head = (int)hash_table[hh];
+        if (head > 0 && p - head < kWinSize) {
+            d0 = p - head;
+            const uint4_a *e = (const uint4_a *)(chain_table + (size_t)(head & kWinMask) * kHcLinks);
+            uint4_a *r = (uint4_a *)(rows + lane * kHcLinks);
+#pragma unroll
+            for (int q = 0; q < kHcLinks / 8; q++) r[q] = e[q];
+        }
+    }
+    if (ride && pre.head > 0 && pre.pos - pre.head < kWinSize)
+        pre.l = chain_table[(size_t)(pre.head & kWinMask) * kHcLinks + lane];
+    __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    for (int i = 0; i < cnt; i++) {
+        const int t = __builtin_amdgcn_readlane(twin, i);
+        const uint32_t d = (uint32_t)__builtin_amdgcn_readlane(d0, i);
+        const int pi = __builtin_amdgcn_readlane(p, i);
+        uint32_t l = 0;
+        if (d != 0) {
+            uint32_t inh = 0;
+            if (lane > 0) inh = rows[(t >= 0 ? t : i) * kHcLinks + lane - 1];
+            l = hc_link(d, inh, lane);
+        }
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // row i was read before it is overwritten
+        rows[i * kHcLinks + lane] = (uint16_t)l;
+        chain_table[(size_t)(pi & kWinMask) * kHcLinks + lane] = (uint16_t)l;
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // a later twin reads this row
+    }
+    if (act && !later) hash_table[hh] = (uint32_t)p;
+    __syncthreads();  // the next round gathers what this one stored
+}
+
 __device__ __forceinline__ void hc_insert_run(uint32_t *hash_table, uint16_t *chain_table,
                                               const uint8_t *__restrict__ s, int p0, int n,
                                               int lane, uint16_t *rows, HcPre &pre) {
-    typedef uint4 __attribute__((may_alias)) uint4_a;
     for (int base = 0; base < n; base += kWave) {
         const int cnt = n - base < kWave ? n - base : kWave;
-        const bool act = lane < cnt;
         const int p = p0 + base + lane;
         const bool ride = base == 0 && pre.pos >= 0;
         if (ride) pre.w = ld64(s + pre.pos);
-        const uint32_t hh = act ? hash4(ld32(s + p)) : 0xFFFFFFFFu;
-        if (ride) {
-            pre.h = hash4((uint32_t)pre.w);
-            pre.head = (int)hash_table[pre.h];
-            pre.l = 0;
-            pre.ok = true;
-        }
-        if (pre.pos >= 0 && ballot(act && hh == pre.h)) pre.ok = false;
-        int twin = -1;        // nearest earlier lane with my hash
-        bool later = false;   // a later lane has my hash: it, not I, ends up in the table
-        for (int i = 0; i < cnt; i++) {
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)hh, i);
-            if (act && hh == hi) {
-                if (lane > i) twin = i;
-                if (lane < i) later = true;
-            }
-        }
-        // distance to the position I link to: the twin, or the table's head (0: none)
-        int d0 = twin >= 0 ? lane - twin : 0;
-        if (act && twin < 0) {
-            const int head = (int)hash_table[hh];
-            if (head > 0 && p - head < kWinSize) {
-                d0 = p - head;
-                const uint4_a *e = (const uint4_a *)(chain_table + (size_t)(head & kWinMask) * kHcLinks);
-                uint4_a *r = (uint4_a *)(rows + lane * kHcLinks);
-#pragma unroll
-                for (int q = 0; q < kHcLinks / 8; q++) r[q] = e[q];
-            }
-        }
-        if (ride && pre.head > 0 && pre.pos - pre.head < kWinSize)
-            pre.l = chain_table[(size_t)(pre.head & kWinMask) * kHcLinks + lane];
-        __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        for (int i = 0; i < cnt; i++) {
-            const int t = __builtin_amdgcn_readlane(twin, i);
-            const uint32_t d = (uint32_t)__builtin_amdgcn_readlane(d0, i);
-            uint32_t l = 0;
-            if (d != 0) {
-                uint32_t inh = 0;
-                if (lane > 0) inh = rows[(t >= 0 ? t : i) * kHcLinks + lane - 1];
-                l = hc_link(d, inh, lane);
-            }
-            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // row i was read before it is overwritten
-            rows[i * kHcLinks + lane] = (uint16_t)l;
-            chain_table[(size_t)((p0 + base + i) & kWinMask) * kHcLinks + lane] = (uint16_t)l;
-            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // a later twin reads this row
-        }
-        if (act && !later) hash_table[hh] = (uint32_t)p;
-        __syncthreads();  // the next round gathers what this one stored
+        const uint32_t hh = lane < cnt ? hash4(ld32(s + p)) : 0u;
+        hc_insert_round(hash_table, chain_table, s, p, hh, cnt, lane, rows, pre, ride);
     }
 }
 
@@ -225,6 +242,15 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
         const int sn = n - kMfLimit;
         bool failed = false;
 
+        // The positions under a match are not inserted at once but collected, up to 64 of them
+        // (lane k: pd_pos, pd_h), and inserted together in ONE round -- its three dependent
+        // fetches are what an insertion costs, however few positions it has, and text matches
+        // are short.  Nothing can tell the difference: a chain only holds positions of one
+        // hash, so a search flushes the pending positions first if one of them has ITS hash
+        // (or if the oldest is 32 KiB back: its entry slot must not wait for the ring to come
+        // round), and positions of different hashes may be inserted in any order.
+        int pd_n = 0, pd_pos = 0;
+        uint32_t pd_h = 0;
         HcPre pre;
         pre.pos = -1;
         pre.ok = false;
@@ -238,6 +264,17 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
             const uint64_t w = ridden ? pre.w : ld64(s + si);
             uint32_t match = (uint32_t)w;
             const uint32_t h = ridden ? pre.h : hash4(match);
+            if (pd_n && (ballot(lane < pd_n && pd_h == h) ||
+                         si - __builtin_amdgcn_readlane(pd_pos, 0) >= (kWinSize >> 1))) {
+                HcPre none;
+                none.pos = -1;
+                none.ok = false;
+                none.w = 0;
+                none.h = none.l = 0;
+                none.head = 0;
+                hc_insert_round(hash_table, chain_table, s, pd_pos, pd_h, pd_n, lane, rows, none, false);
+                pd_n = 0;
+            }
             int m_len = 0, offset = 0;
             uint32_t my_link = 0;  // lane j: link j of si's own chain entry (from the first batch)
             {
@@ -317,10 +354,51 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                 const int end = si + m_len;
                 pre.pos = -1;
                 if (wsn <= si + 1) {
-                    if (end < sn) pre.pos = end;
-                    hc_insert_run(hash_table, chain_table, s, p, end - p, lane, rows, pre);
-                    if (pre.h == h) pre.ok = false;  // si itself is then the head
+                    const int cntp = end - p;
+                    if (end < sn) pre.pos = end;  // the search behind this match may ride along
+                    if (cntp >= kWave) {
+                        // a long match: the pending ones, then the run itself, now
+                        HcPre none;
+                        none.pos = -1;
+                        none.ok = false;
+                        none.w = 0;
+                        none.h = none.l = 0;
+                        none.head = 0;
+                        if (pd_n)
+                            hc_insert_round(hash_table, chain_table, s, pd_pos, pd_h, pd_n, lane, rows, none, false);
+                        pd_n = 0;
+                        hc_insert_run(hash_table, chain_table, s, p, cntp, lane, rows, pre);
+                    } else {
+                        if (pd_n + cntp > kWave) {
+                            // no room: the pending ones go in now, with the next search riding along
+                            if (pre.pos >= 0) pre.w = ld64(s + pre.pos);
+                            hc_insert_round(hash_table, chain_table, s, pd_pos, pd_h, pd_n, lane, rows, pre,
+                                            pre.pos >= 0);
+                            pd_n = 0;
+                        } else {
+                            pre.pos = -1;
+                        }
+                        if (lane >= pd_n && lane < pd_n + cntp) {
+                            pd_pos = p + lane - pd_n;
+                            pd_h = hash4(ld32(s + pd_pos));
+                        }
+                        pd_n += cntp;
+                        // a pending position with the next search's hash: that search will flush
+                        // first, and what rode along was read before the flush
+                        if (pre.pos >= 0 && ballot(lane < pd_n && pd_h == pre.h)) pre.ok = false;
+                    }
+                    if (pre.pos >= 0 && pre.h == h) pre.ok = false;  // si itself is then the head
                 } else {
+                    if (pd_n) {
+                        HcPre none;
+                        none.pos = -1;
+                        none.ok = false;
+                        none.w = 0;
+                        none.h = none.l = 0;
+                        none.head = 0;
+                        hc_insert_round(hash_table, chain_table, s, pd_pos, pd_h, pd_n, lane, rows, none, false);
+                        pd_n = 0;
+                    }
                     // The reference rolls the 4-byte value from the one at si
                     // (:399-400).  When the window clamp skips positions (match
                     // longer than 64 KiB) the first three values mix old and new
