@@ -121,7 +121,18 @@ struct HcPre {
 };
 
 // One round: up to 64 positions in increasing order, lane i <-> pos (with its hash hh), not
-// necessarily consecutive.
+// necessarily consecutive.  A position without a twin depends on nothing in the round: its
+// lane gathers head and head's entry into REGISTERS (all fetches in flight together), derives
+// its own 64 links there and puts the finished row into LDS.  Twins are finished in order
+// afterwards, the wave one link per lane, from their twin's finished row (a run of equal bytes
+// resolves at LDS latency).  The finished rows leave 16 bytes per lane.
+constexpr int kRowStride = kHcLinks + 8;  // u16 units: 144-byte rows spread the lanes' 16-byte accesses over the banks
+
+__device__ __forceinline__ uint32_t hc_shift(uint32_t x, uint32_t d0) {  // one link of the head, seen from d0 further on
+    const uint32_t t = x + d0;
+    return (x != 0 && t < (uint32_t)kWinSize) ? t : 0u;
+}
+
 __device__ __forceinline__ void hc_insert_round(uint32_t *hash_table, uint16_t *chain_table,
                                                 const uint8_t *__restrict__ s, const int p,
                                                 const uint32_t hh_in, const int cnt, const int lane,
@@ -145,44 +156,66 @@ __device__ __forceinline__ void hc_insert_round(uint32_t *hash_table, uint16_t *
             if (lane < i) later = true;
         }
     }
-    // distance to the position I link to: the twin, or the table's head (0: none, or out of
-    // the window -- the reference's walk stops there, :355)
-    int d0 = 0;
     const int twin_pos = __shfl(p, twin < 0 ? lane : twin);  // every lane takes part in the shuffle
-    if (twin >= 0) {
-        d0 = p - twin_pos;
-        if (d0 >= kWinSize) d0 = 0;
-    }
+    // ---- positions without a twin: head's entry -> own entry, in registers ----
     if (act && twin < 0) {
+        uint32_t e[kHcLinks / 2];  // two links per word
+#pragma unroll
+        for (int k = 0; k < kHcLinks / 2; k++) e[k] = 0;
         const int head = (int)hash_table[hh];
         if (head > 0 && p - head < kWinSize) {
-            d0 = p - head;
-            const uint4_a *e = (const uint4_a *)(chain_table + (size_t)(head & kWinMask) * kHcLinks);
-            uint4_a *r = (uint4_a *)(rows + lane * kHcLinks);
+            const uint32_t d0 = (uint32_t)(p - head);
+            const uint4_a *g = (const uint4_a *)(chain_table + (size_t)(head & kWinMask) * kHcLinks);
 #pragma unroll
-            for (int q = 0; q < kHcLinks / 8; q++) r[q] = e[q];
+            for (int q = 0; q < kHcLinks / 8; q++) {
+                const uint4 v = g[q];
+                e[4 * q] = v.x, e[4 * q + 1] = v.y, e[4 * q + 2] = v.z, e[4 * q + 3] = v.w;
+            }
+            // word k of the new entry = links 2k, 2k+1 = the head's links 2k-1, 2k moved by d0
+#pragma unroll
+            for (int k = kHcLinks / 2 - 1; k > 0; k--)
+                e[k] = hc_shift(e[k - 1] >> 16, d0) | (hc_shift(e[k] & 0xFFFFu, d0) << 16);
+            e[0] = d0 | (hc_shift(e[0] & 0xFFFFu, d0) << 16);
         }
+        uint4_a *r = (uint4_a *)(rows + lane * kRowStride);
+#pragma unroll
+        for (int q = 0; q < kHcLinks / 8; q++) r[q] = make_uint4(e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]);
     }
     if (ride && pre.head > 0 && pre.pos - pre.head < kWinSize)
         pre.l = chain_table[(size_t)(pre.head & kWinMask) * kHcLinks + lane];
-    __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    for (int i = 0; i < cnt; i++) {
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ---- twins, in position order: from the twin's finished row (LDS operations of one wave
+    // execute in order, so a row written by one step is what the next step reads) ----
+    uint64_t TW = ballot(act && twin >= 0);
+    while (TW) {
+        const int i = __builtin_ctzll(TW);
+        TW &= TW - 1;
         const int t = __builtin_amdgcn_readlane(twin, i);
-        const uint32_t d = (uint32_t)__builtin_amdgcn_readlane(d0, i);
-        const int pi = __builtin_amdgcn_readlane(p, i);
+        // distance to the twin (0: out of the window -- the reference's walk stops there, :355)
+        uint32_t d = (uint32_t)(__builtin_amdgcn_readlane(p, i) - __builtin_amdgcn_readlane(twin_pos, i));
+        if (d >= (uint32_t)kWinSize) d = 0;
         uint32_t l = 0;
         if (d != 0) {
             uint32_t inh = 0;
-            if (lane > 0) inh = rows[(t >= 0 ? t : i) * kHcLinks + lane - 1];
+            if (lane > 0) inh = rows[t * kRowStride + lane - 1];
             l = hc_link(d, inh, lane);
         }
-        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // row i was read before it is overwritten
-        rows[i * kHcLinks + lane] = (uint16_t)l;
-        chain_table[(size_t)(pi & kWinMask) * kHcLinks + lane] = (uint16_t)l;
-        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // a later twin reads this row
+        rows[i * kRowStride + lane] = (uint16_t)l;
+        __asm__ volatile("" ::: "memory");
+    }
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ---- the finished rows go out, 16 bytes per lane ----
+#pragma unroll
+    for (int it = 0; it < kHcLinks / 8; it++) {
+        const int c = lane + it * kWave, row = c >> 3, col = c & 7;
+        const int prow = __shfl(p, row);  // all lanes shuffle; only the rows that exist are stored
+        if (row < cnt) {
+            const uint4 v = *(const uint4_a *)(rows + row * kRowStride + col * 8);
+            *(uint4_a *)(chain_table + (size_t)(prow & kWinMask) * kHcLinks + col * 8) = v;
+        }
     }
     if (act && !later) hash_table[hh] = (uint32_t)p;
-    __syncthreads();  // the next round gathers what this one stored
+    __syncthreads();  // the next round gathers what this one stored, and reuses the rows
 }
 
 __device__ __forceinline__ void hc_insert_run(uint32_t *hash_table, uint16_t *chain_table,
@@ -205,7 +238,7 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                                                     int32_t *__restrict__ result,
                                                     uint32_t *__restrict__ ws, size_t nb,
                                                     uint32_t *__restrict__ next_block) {
-    __shared__ __attribute__((aligned(16))) uint16_t rows[kWave * kHcLinks];  // hc_insert_run's staging
+    __shared__ __attribute__((aligned(16))) uint16_t rows[kWave * kRowStride];  // hc_insert_run's staging
     const int lane = lane_id();
     uint32_t *hash_table = ws + (size_t)blockIdx.x * kHcSlotWords;
     uint16_t *chain_table = reinterpret_cast<uint16_t *>(hash_table + (1 << 16));
