@@ -122,8 +122,17 @@ __device__ __forceinline__ int len_tail_size(int len) {  // bytes after the toke
 // extension loads, [6] table puts, [7] windows, [8] refill lines (64 B), [9] input bytes.
 #ifdef LZ4HIP_FAST_STATS
 #define FAST_STAT(i, v) stat[i] += (unsigned long long)(v)
+// shader-clock cycles per phase, summed over the waves: [10] refill, [11] table gather (to the
+// first use of its result), [12] candidate verify + extension, [13] walk, [14] encode, [15] puts
+#define FAST_TIME(i)                                                  \
+    do {                                                              \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        stat[i] += now_ - last_t;                                     \
+        last_t = now_;                                                \
+    } while (0)
 #else
 #define FAST_STAT(i, v)
+#define FAST_TIME(i)
 #endif
 
 template <bool kGlobal, typename TablePtr>
@@ -133,8 +142,9 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
                                            uint8_t *obuf, uint32_t *inuse, const int lane,
                                            unsigned long long *stats = nullptr) {
 #ifdef LZ4HIP_FAST_STATS
-    unsigned long long stat[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stat[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     stat[9] = (unsigned long long)n;
+    unsigned long long last_t = __builtin_readcyclecounter();
 #endif
     const int bound = (int)compress_bound32((uint32_t)n);
     const bool not_compressible = dlen < bound;  // block.go:110
@@ -191,6 +201,7 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
             FAST_STAT(8, (cnt + 63) / 64);
             __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+        FAST_TIME(10);
         const uint8_t *sl = sbuf - sb;  // sl[q] == s[q] for sb <= q < se
         const int p = wbase + lane;
         const bool valid = p >= 0 && p <= sn + 1;
@@ -217,6 +228,9 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
         if (ref >= p) ref -= kWinSize;
         int offv = p - ref;  // > 0 by construction
         const bool offok = valid && offv < kWinSize && ref >= 0;
+#ifdef LZ4HIP_FAST_STATS
+        if (ballot(offok) != 0x5555555555555555ull) FAST_TIME(11);  // (the ballot uses tv: the gather has landed)
+#endif
         const bool f0ok = offok && p + 12 <= sn;  // stride 0 at p+4 runs iff p+4+8 <= sn
         const bool f1ok = offok && p + 20 <= sn;
         const bool bok = offok && ref >= 8;
@@ -307,6 +321,9 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
         // The next window will gather the table for positions wbase+64.. (unless a long
         // match jumps over them): touch those lines now, so that the walk below hides
         // their trip from HBM and the next gather finds them in L2.
+#ifdef LZ4HIP_FAST_STATS
+        if (ballot(m4) != 0x5555555555555557ull) FAST_TIME(12);  // (uses the candidate words)
+#endif
         // ================= Phase B: where are the matches =================
         for (;;) {
             si = (int)rfl((uint32_t)si);
@@ -412,6 +429,7 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
                 pending = true;  // lane 0 of the next window
         }
 
+        FAST_TIME(13);
         // ================= Phase C: encode every sequence of the window =================
         if (FOUND) {
             const bool mine = (FOUND >> lane) & 1;
@@ -475,6 +493,7 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
             }
         }
 
+        FAST_TIME(14);
         // ---- close the window: write this window's puts to the table ----
         if (!failed && !finished) {
             FAST_STAT(6, __builtin_popcountll(P));
@@ -490,6 +509,7 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
             if (kGlobal && kBitmap && ((P >> lane) & 1)) atomicOr(&inuse[h >> 5], 1u << (h & 31));
             __asm__ volatile("" ::: "memory");
         }
+        FAST_TIME(15);
     }
 
     // ---------------- last literals: block.go:258-294 ----------------
@@ -520,7 +540,7 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
     }
 #ifdef LZ4HIP_FAST_STATS
     if (stats && lane == 0)
-        for (int i = 1; i < 10; i++) atomicAdd(&stats[i], stat[i]);
+        for (int i = 1; i < 16; i++) atomicAdd(&stats[i], stat[i]);
 #endif
     return ret;
 }

@@ -181,7 +181,7 @@ int main(int argc, char **argv) {
         else c += bs, raw++;
     }
     if (what == "fast" && ws_bytes >= 256) {  // -DLZ4HIP_FAST_STATS builds: access counts by class
-        unsigned long long st[10];
+        unsigned long long st[16];
         CK(hipMemcpy(st, (uint8_t *)d_ws + ws_bytes - 256, sizeof st, hipMemcpyDeviceToHost));
         if (st[7]) {
             const double per = (double)st[9];  // bytes over all timed repetitions
@@ -190,6 +190,12 @@ int main(int argc, char **argv) {
                     "\"ext_r1\":%.4f,\"ext_rb\":%.4f,\"table_puts\":%.4f,\"refill_lines\":%.4f,\"bytes_per_window\":%.2f}}\n",
                     st[1] / per, st[2] / per, st[3] / per, st[4] / per, st[5] / per, st[6] / per, st[8] / per,
                     per / st[7]);
+            const double tot = (double)(st[10] + st[11] + st[12] + st[13] + st[14] + st[15]);
+            if (tot > 0)
+                fprintf(stderr,
+                        "{\"fast_phase_share\":{\"refill\":%.3f,\"table_gather\":%.3f,\"verify_ext\":%.3f,\"walk\":%.3f,"
+                        "\"encode\":%.3f,\"puts\":%.3f},\"cycles_per_window\":%.0f}\n",
+                        st[10] / tot, st[11] / tot, st[12] / tot, st[13] / tot, st[14] / tot, st[15] / tot, tot / st[7]);
         }
     }
     if (what != "decode") {
