@@ -34,6 +34,24 @@ constexpr int kSetTokens = (kWave + 2) / 3;
 static_assert(kSets <= 8, "the token descriptor is a 16-bit window-relative position");
 static_assert(kReach4 + 16 <= kIn, "a refill must cover one window");
 
+// -DLZ4HIP_DEC_PROF (profiling builds only): shader-clock cycles per phase summed over all
+// waves: [0] refill, [1] pass 1, [2] link, [3] compaction + full parse + scan + bounds,
+// [4] literal and match copies into the stage, [5] in-window matches, [6] flush, [7] windows,
+// [8] serial sequences and the rest.
+#ifdef LZ4HIP_DEC_PROF
+__device__ unsigned long long g_dec_prof[16];
+#define DEC_T(i)                                                      \
+    do {                                                              \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        prof[i] += now_ - last_t;                                     \
+        last_t = now_;                                                \
+    } while (0)
+#define DEC_N(i) prof[i]++
+#else
+#define DEC_T(i)
+#define DEC_N(i)
+#endif
+
 struct Hdr {  // one candidate sequence header
     bool ok;
     int lit, ml, off, lpos, end;  // lpos, end: absolute compressed positions
@@ -105,7 +123,20 @@ __device__ __forceinline__ int decode_block(const uint8_t *__restrict__ in, cons
                              uint8_t *stage, uint8_t *ibuf, uint16_t *desc) {
     const bool split = hist_end != d;
     int si = 0, di = 0, ibase = 0, iend = 0;
+#ifdef LZ4HIP_DEC_PROF
+    unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long last_t = __builtin_readcyclecounter();
+    struct Dump {
+        unsigned long long *p;
+        int lane;
+        __device__ ~Dump() {
+            if (lane == 0)
+                for (int i = 0; i < 12; i++) atomicAdd(&g_dec_prof[i], p[i]);
+        }
+    } dump{prof, lane};
+#endif
     for (;;) {
+        DEC_T(8);
         si = (int)rfl((uint32_t)si);
         di = (int)rfl((uint32_t)di);
         if (si >= n) return di;
@@ -128,6 +159,8 @@ __device__ __forceinline__ int decode_block(const uint8_t *__restrict__ in, cons
             lds_sync();
         }
         const uint8_t *ib = ibuf - ibase;  // ib[p] = in[p] for ibase <= p < iend
+        DEC_T(0);
+        DEC_N(7);
 
         // ---------------- pass 1: where would a sequence starting at each byte end ----------------
         // set j, lane l <-> position si + 64 j + l
@@ -146,6 +179,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *__restrict__ in, cons
             continue;
         }
 
+        DEC_T(1);
         // ---------------- link the real tokens (wave-uniform) ----------------
         uint64_t T[kSets];
         {
@@ -194,6 +228,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *__restrict__ in, cons
             }
         }
 
+        DEC_T(2);
         // ---------------- compact: token r of the window -> lane r ----------------
         int ntok = 0;
         lds_sync();  // the previous window's descriptor reads are done
@@ -244,19 +279,26 @@ __device__ __forceinline__ int decode_block(const uint8_t *__restrict__ in, cons
         const int adv_c = (int)rdl((uint32_t)endrel, ntok - 1);            // compressed bytes consumed
         const int adv_o = (int)rdl((uint32_t)(myout + outlen), ntok - 1);  // output bytes produced
 
+        DEC_T(3);
         // ---------------- pass 2: copies ----------------
         if (adv_o <= kStage) {
             lds_sync();  // the previous window's flush has read the stage
             // literals (16 bytes readable after every token: ok => pos + 18 <= n)
             if (act && lit > 0) s2s_over(stage + myout, ib + lpos, lit);
+            lds_sync();
+            DEC_T(9);  // literals
             // leading g bytes of every match come from output older than this window
             int g = 0;
             if (act) {
                 g = off - mstart;
                 g = g < 0 ? 0 : (g > ml ? ml : g);
-                if (g > 0) g2s_exact(stage + mstart, d + di + mstart - off, g);
+                // the source lies before this window's output: dlen - (its offset in the block) may be read
+                if (g > 0) g2s_exact(stage + mstart, d + di + mstart - off, g, dlen - (di + mstart - off));
             }
+            __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            DEC_T(10);  // match bytes fetched
             lds_sync();
+            DEC_T(4);
             // the rest reads this window's own output: stream order, inside the stage
             uint64_t D = ballot(act && g < ml);
             while (D) {
@@ -277,6 +319,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *__restrict__ in, cons
                     lds_sync();
                 }
             }
+            DEC_T(5);
             // flush: 16 bytes per lane, contiguous across the wave
             uint8_t *to = d + di;
             for (int k = lane * 16; k < adv_o; k += kWave * 16) {
@@ -316,6 +359,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *__restrict__ in, cons
                 }
             }
         }
+        DEC_T(6);
         si += adv_c;
         di += adv_o;
     }
@@ -411,6 +455,12 @@ __global__ __launch_bounds__(64) void k_decode_linked(const uint8_t *__restrict_
         else total += (size_t)r;
     }
 }
+
+#ifdef LZ4HIP_DEC_PROF
+extern "C" int lz4hip_debug_dec_prof(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dec_prof), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
 
 hipError_t launch_decode_linked(const uint8_t *src, const uint64_t *off, const uint32_t *sw,
                                 size_t nb, uint8_t *dst, uint32_t block_cap, size_t dst_cap,

@@ -127,7 +127,30 @@ __device__ __forceinline__ void lane_copy16(uint8_t *dst, const uint8_t *src, in
 
 // Exact-length copy of len bytes from global memory into the LDS stage (lane-private;
 // reads exactly [src, src+len)).
-__device__ __forceinline__ void g2s_exact(uint8_t *st, const uint8_t *src, int len) {
+// `room`: bytes that may be READ from src on (>= len; the rest of the block's own dst slot).
+// The wave waits for its slowest lane, and a lane that fetches 16 bytes per round trip needs
+// three of them for a 40-byte match: up to 32 bytes are fetched in ONE round trip (four loads
+// in flight, over-reading inside `room`) and stored exactly.
+__device__ __forceinline__ void g2s_exact(uint8_t *st, const uint8_t *src, int len, int room) {
+    if (len <= 32 && room >= 32) {
+        const uint64_t a0 = ld64(src), a1 = ld64(src + 8), a2 = ld64(src + 16), a3 = ld64(src + 24);
+        uint64_t t = a0;
+        if (len >= 8) {
+            __builtin_memcpy(st, &a0, 8);
+            t = a1;
+            if (len >= 16) {
+                __builtin_memcpy(st + 8, &a1, 8);
+                t = a2;
+                if (len >= 24) {
+                    __builtin_memcpy(st + 16, &a2, 8);
+                    t = a3;
+                    if (len >= 32) __builtin_memcpy(st + 24, &a3, 8);
+                }
+            }
+        }
+        store_tail(st + (len & ~7), t, len & 7);
+        return;
+    }
     while (len >= 16) {
         const uint64_t a = ld64(src), b = ld64(src + 8);
         __builtin_memcpy(st, &a, 8);

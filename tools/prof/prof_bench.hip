@@ -6,6 +6,7 @@
 //
 //   prof_bench TESTDATA_DIR KIND GIB BS_LOG WHAT [REPS] [LEVEL]
 //     KIND  text | binary | mixed | random         WHAT  fast | decode | hc | xxh
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -236,6 +237,22 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(x2.data(), d_x2, nb * 4, hipMemcpyDeviceToHost));
     const bool ok = x1 == x2;
     const size_t cc = end - 4 * nb;
+    {  // -DLZ4HIP_DEC_PROF builds of the library export per-phase cycle sums
+        typedef int (*prof_fn)(unsigned long long *);
+        if (prof_fn f = (prof_fn)dlsym(RTLD_DEFAULT, "lz4hip_debug_dec_prof")) {
+            unsigned long long st[16];
+            if (f(st) == 0 && st[7]) {
+                double tot = 0;
+                for (int i = 0; i < 12; i++) if (i != 7) tot += (double)st[i];
+                fprintf(stderr, "{\"copies_split\":{\"literals\":%.3f,\"match_fetch\":%.3f,\"match_store\":%.3f}}\n", st[9] / tot, st[10] / tot, st[4] / tot);
+                fprintf(stderr,
+                        "{\"decode_phase_share\":{\"refill\":%.3f,\"pass1\":%.3f,\"link\":%.3f,\"compact_parse_scan\":%.3f,"
+                        "\"copies\":%.3f,\"in_window\":%.3f,\"flush\":%.3f,\"other\":%.3f},\"cycles_per_window\":%.0f}\n",
+                        st[0] / tot, st[1] / tot, st[2] / tot, st[3] / tot, st[4] / tot, st[5] / tot, st[6] / tot,
+                        st[8] / tot, tot / st[7]);
+            }
+        }
+    }
     printf("{\"what\":\"decode\",\"kind\":\"%s\",\"n\":%zu,\"bs\":%u,\"blocks\":%zu,\"c\":%zu,\"ms_min\":%.3f,"
            "\"ms_avg\":%.3f,\"GBps\":%.3f,\"alg_GBps\":%.3f,\"roofline_frac\":%.5f,\"round_trip_ok\":%s}\n",
            kind_s.c_str(), n, bs, nb, cc, td.first, td.second, n / (td.first * 1e6), (n + cc) / (td.first * 1e6),
