@@ -285,8 +285,10 @@ __device__ __forceinline__ int decode_block(const uint8_t *__restrict__ in, cons
             lds_sync();  // the previous window's flush has read the stage
             // literals (16 bytes readable after every token: ok => pos + 18 <= n)
             if (act && lit > 0) s2s_over(stage + myout, ib + lpos, lit);
+#ifdef LZ4HIP_DEC_PROF
             lds_sync();
             DEC_T(9);  // literals
+#endif
             // leading g bytes of every match come from output older than this window
             int g = 0;
             if (act) {
@@ -295,8 +297,10 @@ __device__ __forceinline__ int decode_block(const uint8_t *__restrict__ in, cons
                 // the source lies before this window's output: dlen - (its offset in the block) may be read
                 if (g > 0) g2s_exact(stage + mstart, d + di + mstart - off, g, dlen - (di + mstart - off));
             }
+#ifdef LZ4HIP_DEC_PROF
             __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
             DEC_T(10);  // match bytes fetched
+#endif
             lds_sync();
             DEC_T(4);
             // the rest reads this window's own output: stream order, inside the stage
