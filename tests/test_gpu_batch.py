@@ -286,6 +286,28 @@ def test_hc_window_clamp_and_long_range_repeats(T, oracle, depth):
     _check_blocks(T, oracle, data, bs, depth)
 
 
+@pytest.mark.parametrize("depth", [16, 131072])
+def test_hc_waiting_positions_are_inserted_in_time(T, oracle, depth):
+    """The HC kernel collects the positions under matches and inserts them 64 at a time
+    (hc.hip): a search with a waiting position's hash, a full set, a long match and the
+    32 KiB age limit each end the wait.  Blocks built to take each way out: a short repeat,
+    then > 32 KiB of noise (age), then the repeat again -- found through positions that waited;
+    dense short repeats (full sets, hash conflicts); runs longer than 64 (the direct path)."""
+    rng = np.random.default_rng(depth + 3)
+    text = np.frombuffer(load("pg1661.txt"), dtype=np.uint8)
+    bs = 1 << 18
+    a = text[5000:5200]
+    noise = lambda n: rng.integers(0, 256, n, dtype=np.uint8)
+    b0 = np.concatenate([a, a, noise(40000), a, noise(33000), a[:150], a, noise(bs)])[:bs]
+    unit = text[9000:9040]
+    b1 = np.concatenate([np.concatenate([unit[:int(k)], noise(3)]) for k in rng.integers(6, 40, 9000)])[:bs]
+    b2 = np.concatenate([np.concatenate([text[20000:20000 + int(k)], noise(int(j))])
+                         for k, j in zip(rng.integers(60, 400, 900), rng.integers(1, 90, 900))])[:bs]
+    b3 = np.concatenate([a, noise(32768 - 300), a, noise(32768 + 500), a, noise(bs)])[:bs]
+    blocks = [np.concatenate([b, np.zeros(bs - b.size, np.uint8)]) if b.size < bs else b for b in (b0, b1, b2, b3)]
+    _check_blocks(T, oracle, np.concatenate(blocks), bs, depth)
+
+
 def test_sharded_frame_path_world1_device_ops(T, oracle):
     """lz4_amd.shard with the real device ops (world size 1, RCCL backend), both
     directions: span assembly, the hosted and the device content-checksum chain, the
