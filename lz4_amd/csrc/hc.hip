@@ -231,6 +231,24 @@ __device__ __forceinline__ void hc_insert_run(uint32_t *hash_table, uint16_t *ch
     }
 }
 
+// -DLZ4HIP_HC_PROF (profiling builds only, tools/prof): shader-clock cycles summed over all waves,
+// [0..3] searches by batches walked (none, one, 2-8, more), [4] waiting-position bookkeeping and
+// the per-search store, [5] insertion rounds, [6] emission, [7] set-up and tail; counts: [8..11]
+// searches of those four kinds, [12] batches, [13] matches, [14] insertion rounds.
+#ifdef LZ4HIP_HC_PROF
+__device__ unsigned long long g_hc_prof[16];
+#define HC_T(i)                                                       \
+    do {                                                              \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        prof[i] += now_ - last_t;                                     \
+        last_t = now_;                                                \
+    } while (0)
+#define HC_N(i, v) prof[i] += (unsigned long long)(v)
+#else
+#define HC_T(i)
+#define HC_N(i, v)
+#endif
+
 __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ src,
                                                     size_t n_total, uint32_t block_size,
                                                     uint32_t depth, int dst_mode, uint32_t dst_len_x,
@@ -274,6 +292,11 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
         int si = 0, di = 0, anchor = 0;
         const int sn = n - kMfLimit;
         bool failed = false;
+#ifdef LZ4HIP_HC_PROF
+        unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long last_t = __builtin_readcyclecounter();
+        int nbatch = 0;
+#endif
 
         // The positions under a match are not inserted at once but collected, up to 64 of them
         // (lane k: pd_pos, pd_h), and inserted together in ONE round -- its three dependent
@@ -308,6 +331,10 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                 hc_insert_round(hash_table, chain_table, s, pd_pos, pd_h, pd_n, lane, rows, none, false);
                 pd_n = 0;
             }
+            HC_T(4);
+#ifdef LZ4HIP_HC_PROF
+            nbatch = 0;
+#endif
             int m_len = 0, offset = 0;
             uint32_t my_link = 0;  // lane j: link j of si's own chain entry (from the first batch)
             {
@@ -324,6 +351,9 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                 if (in_window(next)) l = ridden ? pre.l : chain_table[(size_t)(next & kWinMask) * kHcLinks + lane];
                 bool first = true;
                 while (tries > 0 && in_window(next) && m_len < ml_max) {
+#ifdef LZ4HIP_HC_PROF
+                    nbatch++;
+#endif
                     // one batch = cur itself (lane 0) and cur's links 0..62 (lanes 1..63);
                     // link 63 starts the next batch
                     const int cur = next;
@@ -369,6 +399,14 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                     l = l_next;
                 }
             }
+#ifdef LZ4HIP_HC_PROF
+            {
+                const int kind = nbatch == 0 ? 0 : nbatch == 1 ? 1 : nbatch <= 8 ? 2 : 3;
+                HC_T(kind);
+                HC_N(8 + kind, 1);
+                HC_N(12, nbatch);
+            }
+#endif
             // hc_insert(si): the entry was derived above (all zero when there was no head
             // inside the window); the head moves to si
             chain_table[(size_t)(si & kWinMask) * kHcLinks + lane] = (uint16_t)my_link;
@@ -444,6 +482,8 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                 __syncthreads();
             }
 
+            HC_T(5);
+            HC_N(13, 1);
             const int l_len = si - anchor;
             si += m_len;
             m_len -= kMinMatch;
@@ -486,6 +526,7 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
                     break;
                 }
             }
+            HC_T(6);
         }
 
         // ---- tail, block.go:452-480.  For sn <= 0 the anchor==0 early-out is
@@ -515,8 +556,19 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
         }
         if (lane == 0) result[b] = ret;
         __syncthreads();
+#ifdef LZ4HIP_HC_PROF
+        HC_T(7);
+        if (lane == 0)
+            for (int i = 0; i < 16; i++) atomicAdd(&g_hc_prof[i], prof[i]);
+#endif
     }
 }
+
+#ifdef LZ4HIP_HC_PROF
+extern "C" int lz4hip_debug_hc_prof(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hc_prof), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
 
 hipError_t launch_hc(const uint8_t *src, size_t n, uint32_t bs, size_t nb, uint32_t depth,
                      int dst_mode,

@@ -199,6 +199,25 @@ int main(int argc, char **argv) {
                         st[10] / tot, st[11] / tot, st[12] / tot, st[13] / tot, st[14] / tot, st[15] / tot, tot / st[7]);
         }
     }
+    if (what == "hc") {  // -DLZ4HIP_HC_PROF builds of the library export per-phase cycle sums
+        typedef int (*prof_fn)(unsigned long long *);
+        if (prof_fn f = (prof_fn)dlsym(RTLD_DEFAULT, "lz4hip_debug_hc_prof")) {
+            unsigned long long st[16];
+            if (f(st) == 0 && st[8] + st[9] + st[10] + st[11]) {
+                double tot = 0;
+                for (int i = 0; i < 8; i++) tot += (double)st[i];
+                const double ns = (double)(st[8] + st[9] + st[10] + st[11]);
+                fprintf(stderr,
+                        "{\"hc_time_share\":{\"search_empty\":%.3f,\"search_1_batch\":%.3f,\"search_2_8\":%.3f,"
+                        "\"search_more\":%.3f,\"store_bookkeeping\":%.3f,\"insertion\":%.3f,\"emit\":%.3f,\"setup_tail\":%.3f},"
+                        "\"search_share\":{\"empty\":%.3f,\"one\":%.3f,\"2_8\":%.4f,\"more\":%.4f},"
+                        "\"batches_per_search\":%.2f,\"matches_per_search\":%.3f,\"cycles_per_search\":%.0f}\n",
+                        st[0] / tot, st[1] / tot, st[2] / tot, st[3] / tot, st[4] / tot, st[5] / tot, st[6] / tot,
+                        st[7] / tot, st[8] / ns, st[9] / ns, st[10] / ns, st[11] / ns, st[12] / ns, st[13] / ns,
+                        tot / ns);
+            }
+        }
+    }
     if (what != "decode") {
         printf("{\"what\":\"%s\",\"kind\":\"%s\",\"n\":%zu,\"bs\":%u,\"blocks\":%zu,\"raw_blocks\":%zu,\"c\":%zu,"
                "\"ms_min\":%.3f,\"ms_avg\":%.3f,\"GBps\":%.3f,\"alg_GBps\":%.3f,\"roofline_frac\":%.5f}\n",
