@@ -551,3 +551,35 @@ def test_host_frame_compress_pipelined_sub_batches(oracle, bs, mib):
     del src, comp, body
     k, back = frame_uncompress(frame, n)
     assert k == n and back == data.tobytes()
+
+
+def test_host_frames_from_concurrent_threads(oracle):
+    """cgo runs every goroutine's call on its own OS thread: six threads call
+    lz4hip_frame_compress / _uncompress at once on 40 MiB each (staged copies: every call leases
+    its own pinned buffers; per-thread streams).  Every frame equals the oracle's and reads back."""
+    import threading
+    from lz4_amd import _lib, corpus
+    n = 40 << 20
+    flags = _lib.F_CONTENT_CHECKSUM | _lib.F_BLOCK_CHECKSUM
+    inputs = [corpus.generate("mixed", 1000 + 7 * t, n + 1000 * t) for t in range(6)]
+    frames, backs, errs = [None] * 6, [None] * 6, []
+
+    def work(t):
+        try:
+            for _ in range(2):
+                frames[t] = frame_compress(inputs[t], 1 << 18, flags)
+                k, back = frame_uncompress(frames[t], inputs[t].size)
+                backs[t] = (k, back)
+        except BaseException as e:  # surfaced in the main thread
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(6)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for t in range(6):
+        assert backs[t][0] == inputs[t].size and backs[t][1] == inputs[t].tobytes()
+    assert frames[0] == oracle.frame_compress(inputs[0], 1 << 18, flags)
+    assert frames[5] == oracle.frame_compress(inputs[5], 1 << 18, flags)
