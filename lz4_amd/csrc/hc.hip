@@ -249,7 +249,7 @@ __device__ unsigned long long g_hc_prof[16];
 #define HC_N(i, v)
 #endif
 
-__global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ src,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_hc_compress(const uint8_t *__restrict__ src,
                                                     size_t n_total, uint32_t block_size,
                                                     uint32_t depth, int dst_mode, uint32_t dst_len_x,
                                                     uint8_t *__restrict__ dst, size_t dst_stride,
@@ -313,11 +313,21 @@ __global__ __launch_bounds__(64) void k_hc_compress(const uint8_t *__restrict__ 
         pre.w = 0;
         pre.h = pre.l = 0;
         pre.head = 0;
+        uint64_t w_last = 0;  // the 8 source bytes read last, at w_pos
+        int w_pos = -8;
         while (si < sn) {
             // fetched beside the last match's insertion
             const bool ridden = pre.ok && pre.pos == si;
             pre.ok = false;
-            const uint64_t w = ridden ? pre.w : ld64(s + si);
+            // after a miss the search moves on by a byte or two: the 4 bytes it needs are in the 8
+            // already read (one round trip less in front of the table lookup)
+            const int w_sh = si - w_pos;
+            const bool held = w_sh >= 0 && w_sh <= 4;
+            const uint64_t w = ridden ? pre.w : held ? w_last >> (8 * w_sh) : ld64(s + si);
+            if (ridden || !held) {
+                w_last = w;
+                w_pos = si;
+            }
             uint32_t match = (uint32_t)w;
             const uint32_t h = ridden ? pre.h : hash4(match);
             if (pd_n && (ballot(lane < pd_n && pd_h == h) ||
