@@ -90,12 +90,22 @@ __device__ __forceinline__ int hc_prefix_len(const uint8_t *s, int next, int si,
     return ml;
 }
 
+// Maximum over the wave, in every lane: DPP row shifts and row broadcasts leave it in lane 63
+// (six v_max with a DPP operand; the shuffle form is six dependent LDS permutes per batch).
 __device__ __forceinline__ int wave_max(int v) {
-    for (int o = 32; o > 0; o >>= 1) {
-        const int t = __shfl_xor(v, o);
-        v = t > v ? t : v;
+#define LZ4HIP_MAX_STEP(ctrl, rows)                                              \
+    {                                                                            \
+        const int t = __builtin_amdgcn_update_dpp(v, v, ctrl, rows, 0xF, false); \
+        v = t > v ? t : v;                                                       \
     }
-    return v;
+    LZ4HIP_MAX_STEP(0x111, 0xF)  // row_shr:1
+    LZ4HIP_MAX_STEP(0x112, 0xF)  // row_shr:2
+    LZ4HIP_MAX_STEP(0x114, 0xF)  // row_shr:4
+    LZ4HIP_MAX_STEP(0x118, 0xF)  // row_shr:8
+    LZ4HIP_MAX_STEP(0x142, 0xA)  // row_bcast:15 -> rows 1, 3
+    LZ4HIP_MAX_STEP(0x143, 0xC)  // row_bcast:31 -> rows 2, 3
+#undef LZ4HIP_MAX_STEP
+    return __builtin_amdgcn_readlane(v, kWave - 1);
 }
 
 // Inserts positions p0 .. p0+n-1 in order (block.go:394-405 without the window clamp:
@@ -315,6 +325,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
         pre.head = 0;
         uint64_t w_last = 0;  // the 8 source bytes read last, at w_pos
         int w_pos = -8;
+        // A sequence's literals (up to 64) are read at emission and stored at the end of the next
+        // search, one byte per lane: a wave's loads return in order, so they have arrived with
+        // that search's own loads, and the emission itself waits for nothing.
+        int lit_n = 0, lit_di = 0;
+        uint32_t lit = 0;
+        auto put_literals = [&]() {
+            if (lit_n) {
+                if (lane < lit_n) d[lit_di + lane] = (uint8_t)lit;
+                lit_n = 0;
+            }
+        };
         while (si < sn) {
             // fetched beside the last match's insertion
             const bool ridden = pre.ok && pre.pos == si;
@@ -367,7 +388,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                     // one batch = cur itself (lane 0) and cur's links 0..62 (lanes 1..63);
                     // link 63 starts the next batch
                     const int cur = next;
-                    const uint32_t lk = (uint32_t)__shfl_up((int)l, 1);  // lane k: link k-1
+                    // lane k: link k-1 (DPP wave_shr:1; lane 0 gets 0 and does not use it)
+                    const uint32_t lk = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)l, 0x138, 0xF, 0xF, false);
                     const int mine = lane == 0 ? cur : cur - (int)lk;
                     const bool valid = lane == 0 || (lk != 0 && si - mine < kWinSize);
                     if (first) {
@@ -383,12 +405,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                     tries -= (uint32_t)cnt;
                     next = 0;
                     if (nv == kWave && tries > 0) {
-                        const uint32_t l63 = rfl((uint32_t)__shfl((int)l, kWave - 1));
+                        const uint32_t l63 = (uint32_t)__builtin_amdgcn_readlane((int)l, kWave - 1);
                         if (l63 != 0) next = cur - (int)l63;  // window check: loop condition
                     }
                     // the next entry's fetch flies while this batch is compared
-                    uint32_t l_next = 0;
-                    if (in_window(next)) l_next = chain_table[(size_t)(next & kWinMask) * kHcLinks + lane];
+                    // (straight into l, whose old value is used up: through a second variable the
+                    // compiler copies it at once and waits for the fetch right here)
+                    l = 0;
+                    if (in_window(next)) l = chain_table[(size_t)(next & kWinMask) * kHcLinks + lane];
                     int ml = 0;
                     if (lane < cnt) {
                         // The reference's gate (:358-360) as a shortcut once a long match is
@@ -404,9 +428,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                     const int best = wave_max(key);
                     if (best != 0 && (best >> 6) > m_len) {  // strictly longer: :373-379
                         m_len = best >> 6;
-                        offset = si - __shfl(mine, 63 - (best & 63));
+                        offset = si - __builtin_amdgcn_readlane(mine, 63 - (best & 63));
                     }
-                    l = l_next;
                 }
             }
 #ifdef LZ4HIP_HC_PROF
@@ -419,6 +442,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
 #endif
             // hc_insert(si): the entry was derived above (all zero when there was no head
             // inside the window); the head moves to si
+            put_literals();  // behind the search's own loads
             chain_table[(size_t)(si & kWinMask) * kHcLinks + lane] = (uint16_t)my_link;
             if (lane == 0) hash_table[h] = (uint32_t)si;
             __syncthreads();
@@ -517,7 +541,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 failed = true;
                 break;
             }
-            wave_copy(d + di, s + anchor, l_len, lane);
+            if (l_len <= kWave) {
+                if (lane < l_len) lit = s[anchor + lane];
+                lit_n = l_len;
+                lit_di = di;
+            } else {
+                wave_copy(d + di, s + anchor, l_len, lane);
+            }
             di += l_len;
             anchor = si;
             di += 2;
@@ -539,6 +569,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             HC_T(6);
         }
 
+        put_literals();
         // ---- tail, block.go:452-480.  For sn <= 0 the anchor==0 early-out is
         // skipped (goto lastLiterals, :339-341). ----
         int ret;
