@@ -203,7 +203,10 @@ int main(int argc, char **argv) {
         typedef int (*prof_fn)(unsigned long long *);
         if (prof_fn f = (prof_fn)dlsym(RTLD_DEFAULT, "lz4hip_debug_hc_prof")) {
             unsigned long long st[16];
-            if (f(st) == 0 && st[8] + st[9] + st[10] + st[11]) {
+            if (f(st) == 0 && getenv("LZ4HIP_PROF_RAW")) {  // experiment builds that use the slots their own way
+                fprintf(stderr, "{\"hc_raw\":[");
+                for (int k = 0; k < 16; k++) fprintf(stderr, "%llu%s", st[k], k < 15 ? "," : "]}\n");
+            } else if (f(st) == 0 && st[8] + st[9] + st[10] + st[11]) {
                 double tot = 0;
                 for (int i = 0; i < 8; i++) tot += (double)st[i];
                 const double ns = (double)(st[8] + st[9] + st[10] + st[11]);
