@@ -6,6 +6,10 @@
 //
 //   prof_bench TESTDATA_DIR KIND GIB BS_LOG WHAT [REPS] [LEVEL]
 //     KIND  text | binary | mixed | random         WHAT  fast | decode | hc | xxh
+// With a profiling build of the library on LD_LIBRARY_PATH (-DLZ4HIP_FAST_STATS, -DLZ4HIP_DEC_PROF,
+// -DLZ4HIP_HC_PROF: cycle marks inside the kernels) the per-phase shares go to stderr as a second JSON
+// line; LZ4HIP_PROF_RAW=1 prints the HC build's 16 slots as they are (experiment builds that use
+// the slots their own way).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
