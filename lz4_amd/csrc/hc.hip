@@ -423,10 +423,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                         const bool gate = m_len < LZ4HIP_HC_GATE || ld64(s + mine + m_len - 7) == ld64(s + si + m_len - 7);
                         if (gate) ml = hc_prefix_len(s, mine, si, lim);
                     }
-                    // winner: max ml, ties to the earliest chain entry (lowest lane)
-                    const int key = ml >= kMinMatch ? (ml << 6) | (63 - lane) : 0;
-                    const int best = wave_max(key);
-                    if (best != 0 && (best >> 6) > m_len) {  // strictly longer: :373-379
+                    // winner: max ml, ties to the earliest chain entry (lowest lane); only a strictly
+                    // longer candidate replaces the held one (:373-379), and on a long walk most
+                    // batches have none: one ballot says so and the reduction is skipped
+                    if (ballot(ml >= kMinMatch && ml > m_len)) {
+                        const int key = ml >= kMinMatch ? (ml << 6) | (63 - lane) : 0;
+                        const int best = wave_max(key);
                         m_len = best >> 6;
                         offset = si - __builtin_amdgcn_readlane(mine, 63 - (best & 63));
                     }
