@@ -48,10 +48,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size-gib", type=float, default=8.0, help="GiB per corpus per GPU")
-    ap.add_argument("--frame-timeout", type=int, default=180,
+    ap.add_argument("--frame-timeout", type=int, default=240,
                     help="seconds after which the headline is printed without the frame-path section")
-    ap.add_argument("--frame-gib", type=float, default=8.0,
-                    help="GiB per GPU for the cfg5 frame path after the timed region (0: skip)")
+    ap.add_argument("--frame-gib", type=float, default=16.0,
+                    help="GiB per GPU for the cfg5 frame path after the timed region (cfg5's share is 16 "
+                         "GiB = 4096 blocks of 4 MiB; halved while free HBM does not allow it; 0: skip)")
     ap.add_argument("--cpu-sample-mib", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -256,7 +257,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_fast_gtab",
                          "achieved": round(alg_bytes / t_comp / 1e9, 3), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(alg_bytes / t_comp / 1e9 / HBM_PEAK_GBPS, 5),
-                         "traffic": traffic, "random_access": ra,
+                         "traffic": traffic,
+                         "traffic_source": "profiles/traffic.json (rocprofv3 --pmc passes of this workload "
+                                           "at 8 GiB, bytes per input byte) x this launch's input bytes; "
+                                           "not collected in this run",
+                         "random_access": ra,
                          "decode_achieved": round((n + c_text) / t_dec / 1e9, 3),
                          "decode_frac": round((n + c_text) / t_dec / 1e9 / HBM_PEAK_GBPS, 5)},
             "cpu_baseline": cpu,
@@ -282,7 +287,7 @@ def main():
     def bail():
         emit({"error": "the frame path did not finish within %d s" % args.frame_timeout})
         sys.stdout.flush()
-        os._exit(0)
+        os._exit(3)   # a stuck transfer must not reach the driver as a successful run
 
     guard = threading.Timer(args.frame_timeout, bail)
     guard.daemon = True
@@ -294,11 +299,25 @@ def main():
         try:
             from lz4_amd import shard
             BS_F = 1 << 22
-            share = min(int(args.frame_gib * (1 << 30)), n) // BS_F * BS_F
-            src_f = mixed[:share]               # this rank's block range of the stream
-            n_total = share * world
-            del comp, out
+            del comp, out, packed, text
             torch.cuda.empty_cache()
+            share = int(args.frame_gib * (1 << 30)) // BS_F * BS_F
+            # source + slots + entries + frame + decoded copy: ~5x the share must fit
+            while share > BS_F and torch.cuda.mem_get_info(device)[0] < 5 * share + (8 << 30):
+                share = share // 2 // BS_F * BS_F
+            if share <= n:
+                src_f = mixed[:share]               # this rank's block range of the stream
+            else:
+                del mixed
+                torch.cuda.empty_cache()
+                src_f = torch.empty(share, dtype=torch.uint8, device=device)
+                for a in range(0, share, 1 << 24):
+                    c = min(1 << 24, share - a)
+                    src_f[a:a + c] = corpus.generate("mixed", rank * share + a, c, xp=torch, device=device,
+                                                     bases=bases)
+            n_total = share * world
+            if rank > 0:
+                shard.reserve_staging(share)    # pinned memory of the checksum relay, outside the timing
             fp = {"write_GBps": {}, "read_GBps": {}, "phases_s": {}}
             ok_rt = True
             for label, flags in (("no_content_checksum", 1), ("content_checksum", 3)):
@@ -330,9 +349,9 @@ def main():
             flag = torch.tensor([1 if ok_rt else 0], dtype=torch.int64, device="cpu" if one_dev else device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             fp["round_trip_equals_source"] = bool(flag.item())
-            fp["workload"] = ("cfg5 share: %.2f GiB/GPU of the mixed corpus, 4MB blocks, xxh32 block checksums, "
-                              "Writer + Reader through lz4_amd.shard; content checksum chain on the host"
-                              % (share / 2**30))
+            fp["workload"] = ("cfg5 share: %.2f GiB/GPU (%d blocks/GPU) of the mixed corpus, 4MB blocks, xxh32 "
+                              "block checksums, Writer + Reader through lz4_amd.shard; content checksum chain "
+                              "on the host" % (share / 2**30, share // BS_F))
             frame_path = fp
         except Exception as e:  # the headline line must survive a failure of this extra section
             frame_path = {"error": "%s: %s" % (type(e).__name__, e)}

@@ -120,7 +120,11 @@ int lz4hip_compress_fast_blocks(const void *d_src, size_t n, uint32_t block_size
  * output bytes as lz4hip_compress_fast_blocks.  n is limited to LZ4HIP_NOALLOC_MAX_BYTES; a
  * larger n is rejected with LZ4HIP_ERR_ARG before anything is launched.  Every call on a GPU
  * shares that GPU's array: calls that overlap on one GPU (different streams or threads)
- * race on it and must be serialised by the caller. */
+ * race on it and must be serialised by the caller.
+ * Under stream capture: the FIRST call on a device resolves the array's address
+ * (hipGetSymbolAddress: loads the module, takes a lock) and must not happen inside a
+ * capture -- call lz4hip_init(device), or make one call outside the capture, first.  After
+ * that a call only enqueues a 4-byte hipMemsetAsync and one kernel, both capturable. */
 #define LZ4HIP_NOALLOC_MAX_BYTES (4ull << 30)
 int lz4hip_compress_fast_blocks_noalloc(const void *d_src, size_t n, uint32_t block_size,
                                         int dst_mode, void *d_dst, size_t dst_stride,
@@ -182,6 +186,13 @@ int lz4hip_xxh32_stream_update(const void *d_src, size_t n, uint32_t *d_state, i
  * variant the sharded frame path uses for ChecksumOption(true). */
 int lz4hip_xxh32_stream_update_host(const void *d_src, size_t n, uint32_t *h_state, int first,
                                     int final_piece, uint32_t *h_digest, void *stream);
+/* The same step over bytes that already are in HOST memory (XXHZero.Write / Sum32,
+ * xxh32zero.go:58-139, on the calling thread; no GPU involved).  A rank of the sharded frame
+ * path that waits for the state of the ranks before it stages its shard into pinned host
+ * memory meanwhile, so that its turn in the chain is the hash alone
+ * (lz4stream/block.go:257-259 is serial by construction). */
+int lz4hip_xxh32_host_update(const void *h_src, size_t n, uint32_t *h_state, int first,
+                             int final_piece, uint32_t *h_digest);
 
 /* Frame assembly on device: FrameDescriptor.Write (frame.go:144-167),
  * FrameDataBlock.Write per block (lz4stream/block.go:254-276: size word,

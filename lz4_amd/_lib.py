@@ -44,6 +44,7 @@ SYMBOLS = {
     "lz4hip_xxh32_stream": (_int, [_vp, _sz, _vp, _vp]),
     "lz4hip_xxh32_stream_update": (_int, [_vp, _sz, _vp, _int, _int, _vp, _vp]),
     "lz4hip_xxh32_stream_update_host": (_int, [_vp, _sz, _vp, _int, _int, _vp, _vp]),
+    "lz4hip_xxh32_host_update": (_int, [_vp, _sz, _vp, _int, _int, _vp]),
     "lz4hip_frame_layout": (_int, [_vp, _sz, _u32, _sz, _vp, _u64, _vp, _vp, _vp]),
     "lz4hip_frame_scatter": (_int, [_vp, _sz, _u32, _vp, _sz, _vp, _vp, _vp, _sz, _vp, _u64, _vp]),
     "lz4hip_frame_index": (_int, [_vp, _sz, _u64, _u32, _int, _sz, _vp, _vp, _vp, _vp, _vp]),

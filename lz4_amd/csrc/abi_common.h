@@ -144,6 +144,8 @@ public:
             }
             if (a < n) {
                 const size_t m = std::min(kPiece, n - a);
+                // (an upload of an earlier call may still be reading this buffer)
+                if ((e = hipEventSynchronize(ev_[k])) != hipSuccess) break;
                 if ((e = hipMemcpyAsync(pin_[k], static_cast<const uint8_t *>(d) + a, m, hipMemcpyDeviceToHost, st)) != hipSuccess) break;
                 e = hipEventRecord(ev_[k], st);
                 at[k] = a, len[k] = m;
@@ -161,6 +163,30 @@ public:
     hipError_t down(void *h, const void *d, size_t n, hipStream_t st) {
         return down(h, d, n, st, [](size_t) {});
     }
+    // d[0,n) handed to piece(ptr, len) in order, in the pinned buffers themselves (no copy to
+    // pageable memory): one piece is on the bus while the caller works on the other.
+    template <class F> hipError_t drain(const void *d, size_t n, hipStream_t st, F &&piece) {
+        if (!n) return hipSuccess;
+        hipError_t e = ready();
+        if (e != hipSuccess) return e;
+        const uint8_t *src = static_cast<const uint8_t *>(d);
+        const size_t pieces = (n + kPiece - 1) / kPiece;
+        auto fetch = [&](size_t k) -> hipError_t {
+            const size_t at = k * kPiece, len = std::min(kPiece, n - at);
+            hipError_t f = hipEventSynchronize(ev_[k & 1]);
+            if (f == hipSuccess) f = hipMemcpyAsync(pin_[k & 1], src + at, len, hipMemcpyDeviceToHost, st);
+            return f != hipSuccess ? f : hipEventRecord(ev_[k & 1], st);
+        };
+        e = fetch(0);
+        for (size_t k = 0; k < pieces && e == hipSuccess; k++) {
+            // piece k+1 goes into the buffer that piece k-1 was consumed from
+            if (k + 1 < pieces && (e = fetch(k + 1)) != hipSuccess) break;
+            if ((e = hipEventSynchronize(ev_[k & 1])) != hipSuccess) break;
+            piece(pin_[k & 1], std::min(kPiece, n - k * kPiece));
+        }
+        if (e != hipSuccess) (void)hipStreamSynchronize(st);
+        return e;
+    }
 
     // One Stager for the duration of a call, from the free list of the current device.
     class Lease {
@@ -176,6 +202,9 @@ public:
             if (!s_) s_ = new Stager();
         }
         ~Lease() {
+            // up() returns once the host bytes have been read; its last pieces may still be on
+            // the bus out of pin_[].  The next lessee must not find them in use.
+            s_->settle();
             std::lock_guard<std::mutex> g(mu());
             idle()[dev_ & 63].push_back(s_);
         }
@@ -202,6 +231,11 @@ public:
             }
             if (pin_[i]) (void)hipHostFree(pin_[i]);
         }
+    }
+
+    void settle() {
+        for (int i = 0; i < 2; i++)
+            if (ev_[i]) (void)hipEventSynchronize(ev_[i]);
     }
 
 private:

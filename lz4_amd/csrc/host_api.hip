@@ -288,7 +288,8 @@ static int64_t frame_compress(const uint8_t *src, size_t n, uint32_t block_size,
     HIPCHK(d_xxh.alloc((S.nb + 1) * sizeof(uint32_t)));
     HIPCHK(d_sw.alloc((S.nb + 1) * sizeof(uint32_t)));
     HIPCHK(d_off.alloc((S.nb + 1) * sizeof(uint64_t)));
-    HIPCHK(d_frame.alloc(dst_cap));
+    // the frame's own bound, not the caller's capacity (a generous or reused dst costs nothing)
+    HIPCHK(d_frame.alloc(lz4hip_frame_bound(n, block_size, flags)));
     B.ws_bytes = batch_ws_bytes(level, S.nb_data);
     if (B.ws_bytes) HIPCHK(d_ws.alloc(B.ws_bytes));
     B.src = d_src.as<uint8_t>(), B.comp = d_comp.as<uint8_t>(), B.frame = d_frame.as<uint8_t>();
@@ -398,7 +399,7 @@ static int64_t legacy_uncompress(const uint8_t *src, size_t n, size_t si, uint8_
                 HIPCHK(d_off.alloc(kLegacyChunk * 8));
                 HIPCHK(d_sw.alloc(kLegacyChunk * 4));
                 HIPCHK(d_len.alloc(kLegacyChunk * 4));
-                Stager::Lease stage;
+                Stager::Lease stage;  // (the lease's end waits for the last piece to leave its buffers)
                 HIPCHK(stage->up(d_src.p, src, n, kHostStream));
                 uploaded = true;
             }
@@ -751,16 +752,6 @@ int lz4hip_xxh32_stream_update_host(const void *d_src, size_t n, uint32_t *h_sta
         return fail(LZ4HIP_ERR_ARG, "null pointer");
     if (!final_piece && (n & 15))
         return fail(LZ4HIP_ERR_ARG, "a non-final piece must be a multiple of 16 bytes");
-    constexpr size_t kPiece = 32u << 20;
-    struct Pinned {  // per calling thread, kept for the next call
-        uint8_t *buf[2] = {nullptr, nullptr};
-        hipEvent_t ev[2] = {nullptr, nullptr};
-    };
-    static thread_local Pinned P;
-    for (int i = 0; i < 2; i++) {
-        if (!P.buf[i]) HIPCHK(hipHostMalloc((void **)&P.buf[i], kPiece, hipHostMallocDefault));
-        if (!P.ev[i]) HIPCHK(hipEventCreateWithFlags(&P.ev[i], hipEventDisableTiming));
-    }
     HostXXH x;
     if (!first) {
         memcpy(x.v, h_state, 16);
@@ -768,20 +759,34 @@ int lz4hip_xxh32_stream_update_host(const void *d_src, size_t n, uint32_t *h_sta
         // a state handed over with totalLen 0 would be reset by the next Write
         // (xxh32zero.go:59-61), exactly as the reference's would
     }
-    hipStream_t st = (hipStream_t)stream;
-    const uint8_t *src = static_cast<const uint8_t *>(d_src);
-    const size_t pieces = (n + kPiece - 1) / kPiece;
-    auto fetch = [&](size_t k) -> hipError_t {
-        const size_t at = k * kPiece, len = std::min(kPiece, n - at);
-        hipError_t e = hipMemcpyAsync(P.buf[k & 1], src + at, len, hipMemcpyDeviceToHost, st);
-        return e != hipSuccess ? e : hipEventRecord(P.ev[k & 1], st);
-    };
-    if (pieces) HIPCHK(fetch(0));
-    for (size_t k = 0; k < pieces; k++) {
-        if (k + 1 < pieces) HIPCHK(fetch(k + 1));
-        HIPCHK(hipEventSynchronize(P.ev[k & 1]));
-        x.write(P.buf[k & 1], std::min(kPiece, n - k * kPiece));
+    // The pinned buffers and events are a leased Stager's (per device, kept on the free list
+    // between calls and released by lz4hip_shutdown): nothing is tied to the calling thread.
+    {
+        Stager::Lease stage;
+        HIPCHK(stage->drain(d_src, n, (hipStream_t)stream,
+                            [&](const uint8_t *p, size_t len) { x.write(p, len); }));
     }
+    memcpy(h_state, x.v, 16);
+    h_state[4] = (uint32_t)x.total;
+    h_state[5] = (uint32_t)(x.total >> 32);
+    if (final_piece) *h_digest = x.sum32();
+    return LZ4HIP_OK;
+}
+
+// The same chain step over bytes that already are in host memory (a shard staged into pinned
+// memory while its rank waited for the state): XXHZero.Write / Sum32 and nothing else.
+int lz4hip_xxh32_host_update(const void *h_src, size_t n, uint32_t *h_state, int first,
+                             int final_piece, uint32_t *h_digest) {
+    if (!h_state || (!h_src && n) || (final_piece && !h_digest))
+        return fail(LZ4HIP_ERR_ARG, "null pointer");
+    if (!final_piece && (n & 15))
+        return fail(LZ4HIP_ERR_ARG, "a non-final piece must be a multiple of 16 bytes");
+    HostXXH x;
+    if (!first) {
+        memcpy(x.v, h_state, 16);
+        x.total = (uint64_t)h_state[4] | ((uint64_t)h_state[5] << 32);
+    }
+    x.write(static_cast<const uint8_t *>(h_src), n);
     memcpy(h_state, x.v, 16);
     h_state[4] = (uint32_t)x.total;
     h_state[5] = (uint32_t)(x.total >> 32);

@@ -153,6 +153,17 @@ def xxh32_stream_update_host(src, n, state, first, final):
     return digest.value if final else None
 
 
+def xxh32_host_update(h_src, n, state, first, final):
+    """One step of the chained checksum over bytes that already are in HOST memory (h_src:
+    CPU uint8 tensor, e.g. a shard staged into pinned memory); state: HOST int32[6]."""
+    import ctypes
+    digest = ctypes.c_uint32()
+    _lib.check(_lib.load().lz4hip_xxh32_host_update(
+        h_src.data_ptr() if n else None, n, state.data_ptr(), int(first), int(final),
+        ctypes.addressof(digest) if final else None))
+    return digest.value if final else None
+
+
 def frame_index(frame, n, first_off, block_size, block_checksums, max_blocks):
     """Block index of a standard frame in device memory (lz4stream/block.go:279-317).
     Returns (src_off int64 [max_blocks], size_words int32, want_xxh int32, info int64[4]);

@@ -87,6 +87,24 @@ class DeviceOps:
         state.copy_(st.cpu())
         return (int(dg.item()) & 0xFFFFFFFF) if final else None
 
+    def stage_ahead(self, src, n):
+        """Starts bringing src[:n] down into pinned host memory on a side stream and returns at
+        once.  For a rank that has to wait for the XXHZero state of the ranks before it
+        (lz4stream/block.go:257-259: the chain is serial): when the state arrives its turn is
+        the hash alone, not download + hash."""
+        if self.checksum_on != "host" or not src.is_cuda or n == 0:
+            return None
+        return _StageAhead(src, n)
+
+    def xxh32_update_staged(self, staged, src, n, state, first, final):
+        """xxh32_update over a shard whose first staged.m bytes are in host memory."""
+        m = staged.wait()
+        rest = n - m
+        dg = self.d.xxh32_host_update(staged.buf, m, state, first, final and rest == 0)
+        if rest:
+            dg = self.d.xxh32_stream_update_host(src[m:], rest, state, False, final)
+        return dg
+
     def header(self, bs, flags, content_size):
         hdr = torch.zeros(16, dtype=torch.uint8)
         k = _lib.load().lz4hip_frame_header(hdr.data_ptr(), bs, flags, content_size)
@@ -113,6 +131,39 @@ class DeviceOps:
 
     def pack_blocks(self, out, bs, out_len, flat_off, nb, flat):
         return self.d.pack_blocks(out, bs, out_len, flat_off, nb, flat)
+
+
+_pinned = {}        # device index -> pinned uint8 staging tensor, kept between calls
+
+
+def reserve_staging(n, device=None):
+    """Pinned host memory for stage_ahead, allocated (page-locking 16 GiB takes seconds) outside
+    the caller's timed region; capped at LZ4_SHARD_STAGE_GIB (default 16) GiB per process."""
+    import os
+    cap = int(float(os.environ.get("LZ4_SHARD_STAGE_GIB", "16")) * (1 << 30)) & ~15
+    m = min(n, cap) & ~15 if n > cap else n
+    key = torch.cuda.current_device() if device is None else device.index
+    buf = _pinned.get(key)
+    if buf is None or buf.numel() < m:
+        _pinned.pop(key, None)
+        buf = torch.empty(max(m, 16), dtype=torch.uint8, pin_memory=True)
+        _pinned[key] = buf
+    return buf, m
+
+
+class _StageAhead:
+    def __init__(self, src, n):
+        self.buf, self.m = reserve_staging(n, src.device)
+        self.side = torch.cuda.Stream(device=src.device)
+        self.side.wait_stream(torch.cuda.current_stream(src.device))     # src is complete there
+        with torch.cuda.stream(self.side):
+            self.buf[:self.m].copy_(src[:self.m], non_blocking=True)
+        self.done = torch.cuda.Event()
+        self.done.record(self.side)
+
+    def wait(self):
+        self.done.synchronize()
+        return self.m
 
 
 class _Wire:
@@ -255,6 +306,8 @@ def frame_compress_sharded(src_local, n_total, block_size, flags=_lib.F_CONTENT_
     bsum, csum = bool(flags & _lib.F_BLOCK_CHECKSUM), bool(flags & _lib.F_CONTENT_CHECKSUM)
 
     ahead = _HashAhead(ops, src_local, n_local, last) if csum and rank == 0 else None
+    # the other ranks wait for the state of those before them: their bytes go down meanwhile
+    staged = ops.stage_ahead(src_local, n_local) if csum and rank > 0 and hasattr(ops, "stage_ahead") else None
     result = torch.zeros(nb + 1, dtype=torch.int32, device=dev)
     comp = None
     if hi > lo:
@@ -303,9 +356,13 @@ def frame_compress_sharded(src_local, n_total, block_size, flags=_lib.F_CONTENT_
     # 3. content checksum: state travels rank 0 -> 1 -> ... -> last (frame.go:69-71)
     if csum:
         state = torch.zeros(6, dtype=torch.int32)
-        dg = wire.relay_state(state, 0, world - 1,
-                              lambda st: ahead.result(st) if ahead is not None else
-                              ops.xxh32_update(src_local, n_local, st, False, last))
+        def step(st):
+            if ahead is not None:
+                return ahead.result(st)
+            if staged is not None:
+                return ops.xxh32_update_staged(staged, src_local, n_local, st, False, last)
+            return ops.xxh32_update(src_local, n_local, st, rank == 0, last)
+        dg = wire.relay_state(state, 0, world - 1, step)
         if rank == root:
             at = total - 4
             frame[at:at + 4] = torch.tensor([dg & 0xFF, dg >> 8 & 0xFF, dg >> 16 & 0xFF, dg >> 24],
@@ -454,8 +511,13 @@ def frame_uncompress_sharded(frame, n, group=None, ops=None, root=0, gather=Fals
         if any(s % 16 for s in sizes[:-1]):
             dg = _relay_ragged(wire, ops, flat, sizes, rank)
         else:
-            dg = wire.relay_state(state, 0, last,
-                                  lambda st: ops.xxh32_update(flat, n_local, st, rank == 0, rank == last))
+            staged = ops.stage_ahead(flat, n_local) if rank > 0 and hasattr(ops, "stage_ahead") else None
+
+            def step(st):
+                if staged is not None:
+                    return ops.xxh32_update_staged(staged, flat, n_local, st, False, rank == last)
+                return ops.xxh32_update(flat, n_local, st, rank == 0, rank == last)
+            dg = wire.relay_state(state, 0, last, step)
         if dg != want_cs:
             raise ShardError(_lib.ERR_FRAME_CHECKSUM)
     clock.mark("checksum_s")

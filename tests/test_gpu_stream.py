@@ -583,3 +583,87 @@ def test_host_frames_from_concurrent_threads(oracle):
         assert backs[t][0] == inputs[t].size and backs[t][1] == inputs[t].tobytes()
     assert frames[0] == oracle.frame_compress(inputs[0], 1 << 18, flags)
     assert frames[5] == oracle.frame_compress(inputs[5], 1 << 18, flags)
+
+
+def test_legacy_upload_beside_staged_downloads(oracle):
+    """A legacy frame larger than one 32 MiB staging piece is uploaded and decoded on one thread
+    while two others run frame_compress / frame_uncompress on 40 MiB (staged downloads): a
+    Stager goes back to the free list only when its own copies have left its pinned buffers
+    (abi_common.h Lease::~Lease), so a download of the next lessee can not overwrite bytes an
+    upload is still reading.  Legacy frames carry no checksum: the decoded bytes are compared."""
+    import threading
+    from lz4_amd import _lib, corpus
+    n_leg = 72 << 20
+    # mostly incompressible, so that the legacy FRAME itself is well above one piece
+    raw = np.concatenate([corpus.generate("random", 5, 48 << 20), corpus.generate("text", 9, n_leg - (48 << 20))])
+    legacy = frame_compress(raw, 0, _lib.F_LEGACY)
+    assert len(legacy) > (40 << 20)
+    flags = _lib.F_CONTENT_CHECKSUM | _lib.F_BLOCK_CHECKSUM
+    others = [corpus.generate("mixed", 300 + t, (40 << 20) + 4096 * t) for t in range(2)]
+    errs, done = [], []
+
+    def leg():
+        try:
+            for _ in range(3):
+                k, back = frame_uncompress(legacy, n_leg)
+                assert k == n_leg and back == raw.tobytes()
+            done.append("legacy")
+        except BaseException as e:
+            errs.append(e)
+
+    def std(t):
+        try:
+            for _ in range(3):
+                f = frame_compress(others[t], 1 << 18, flags)
+                k, back = frame_uncompress(f, others[t].size)
+                assert k == others[t].size and back == others[t].tobytes()
+            done.append(t)
+        except BaseException as e:
+            errs.append(e)
+
+    ts = [threading.Thread(target=leg)] + [threading.Thread(target=std, args=(t,)) for t in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert len(done) == 3
+
+
+def test_stream_update_host_from_short_lived_threads(oracle):
+    """lz4hip_xxh32_stream_update_host from a dozen threads that each live for one call: the
+    pinned buffers are a leased Stager's (freed by lz4hip_shutdown), not the calling thread's,
+    so the process's resident memory does not grow by 64 MiB per thread."""
+    import threading
+    import psutil
+    import torch as T
+    from lz4_amd import corpus, device as dev
+    n = (40 << 20) + 16 * 77
+    data = corpus.generate("mixed", 4242, n)
+    want = oracle.ChecksumZero(data)
+    src = T.from_numpy(data).cuda()
+    got, errs = [], []
+
+    def work():
+        try:
+            state = T.zeros(6, dtype=T.int32)
+            half = (n // 2) & ~15
+            dev.xxh32_stream_update_host(src, half, state, True, False)
+            got.append(dev.xxh32_stream_update_host(src[half:], n - half, state, False, True))
+        except BaseException as e:
+            errs.append(e)
+
+    def one():
+        t = threading.Thread(target=work)
+        t.start()
+        t.join()
+
+    one()
+    one()
+    rss0 = psutil.Process().memory_info().rss
+    for _ in range(12):
+        one()
+    grown = psutil.Process().memory_info().rss - rss0
+    assert not errs, errs
+    assert got and all(g == want for g in got)
+    assert grown < (200 << 20), grown       # 12 x 64 MiB = 768 MiB before the fix
