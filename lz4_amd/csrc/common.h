@@ -97,6 +97,10 @@ __device__ __forceinline__ void wave_copy16(uint8_t *d, const uint8_t *s, int n,
 hipError_t launch_fast(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
                        uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,
                        uint16_t *ws, size_t slots, uint32_t *next_block, hipStream_t st);
+// Few blocks: a team of four waves per block, table in LDS (fast_team.hip).
+hipError_t launch_fast_team(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int dst_mode,
+                            uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result,
+                            hipStream_t st);
 hipError_t launch_hc(const uint8_t *src, size_t n, uint32_t bs, size_t nb, uint32_t depth,
                      int dst_mode,
                      uint32_t dst_len_x, uint8_t *dst, size_t dst_stride, int32_t *result, uint32_t *ws,

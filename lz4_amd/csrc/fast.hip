@@ -52,69 +52,11 @@ static_assert(kSrcHist >= 8 && kSrcHist + 2 * kSrcReach <= kSrcBuf, "a refill mu
 // request).  0: the global table is zeroed at every block start instead and every valid lane
 // gathers -- 3.5 KiB of LDS per wave, so twice as many waves fit a CU.
 constexpr bool kBitmap = LZ4HIP_FAST_BITMAP;
+#ifndef LZ4HIP_FAST_TEAM
+#define LZ4HIP_FAST_TEAM 1   // launches without a workspace (few blocks): a team of waves per block (fast_team.hip)
+#endif
 constexpr bool kGateExt = LZ4HIP_FAST_GATE;     // extension loads only behind a verified candidate
 constexpr bool kCandLds = LZ4HIP_FAST_CANDLDS;  // candidates inside the LDS source buffer are read there
-
-// Lane `l` of `old` takes the wave-uniform value `v` (v_cmp + v_cndmask: the VOP3
-// form of v_writelane_b32 cannot take two SGPR operands on gfx9).
-#define wrlane(old, v, l) ((lane == (l)) ? (v) : (old))
-
-// Lane-private exact copy (no over-read): literals of one sequence.
-__device__ __forceinline__ void lane_copy_exact(uint8_t *dst, const uint8_t *src, int len) {
-    while (len >= 8) {
-        const uint64_t a = ld64(src);
-        __builtin_memcpy(dst, &a, 8);
-        dst += 8;
-        src += 8;
-        len -= 8;
-    }
-    if (len & 4) {
-        const uint32_t a = ld32(src);
-        __builtin_memcpy(dst, &a, 4);
-        dst += 4;
-        src += 4;
-    }
-    if (len & 2) {
-        uint16_t a;
-        __builtin_memcpy(&a, src, 2);
-        __builtin_memcpy(dst, &a, 2);
-        dst += 2;
-        src += 2;
-    }
-    if (len & 1) *dst = *src;
-}
-
-// Lane-private "length - 15" run (block.go:211-219,239-246); returns bytes written.
-__device__ __forceinline__ int lane_len_tail(uint8_t *p, int v) {
-    int k = 0;
-    while (v >= 255) {
-        p[k++] = 0xFF;
-        v -= 255;
-    }
-    p[k++] = (uint8_t)v;
-    return k;
-}
-
-// Exact-length global store of the low `len` (< 8) bytes of v.
-__device__ __forceinline__ void store_tail8(uint8_t *p, uint64_t v, int len) {
-    if (len & 4) {
-        const uint32_t w = (uint32_t)v;
-        __builtin_memcpy(p, &w, 4);
-        p += 4;
-        v >>= 32;
-    }
-    if (len & 2) {
-        const uint16_t w = (uint16_t)v;
-        __builtin_memcpy(p, &w, 2);
-        p += 2;
-        v >>= 16;
-    }
-    if (len & 1) *p = (uint8_t)v;
-}
-
-__device__ __forceinline__ int len_tail_size(int len) {  // bytes after the token for `len`
-    return len >= 0xF ? 1 + (len - 0xF) / 255 : 0;
-}
 
 // -DLZ4HIP_FAST_STATS (profiling builds only, tools/prof): lanes that issue a memory access,
 // by class, summed per block and added to uint64 counters behind the block counter in the
@@ -623,8 +565,12 @@ hipError_t launch_fast(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int
         hipLaunchKernelGGL(k_fast_gtab, dim3((unsigned)grid), dim3(kWave), 0, st, src, n, bs, nb,
                            dst_mode, dst_len_x, dst, dst_stride, result, ws, next_block);
     } else {
+#if LZ4HIP_FAST_TEAM
+        return launch_fast_team(src, n, bs, nb, dst_mode, dst_len_x, dst, dst_stride, result, st);
+#else
         hipLaunchKernelGGL(k_fast_lds, dim3((unsigned)nb), dim3(kWave), 0, st, src, n, bs,
                            dst_mode, dst_len_x, dst, dst_stride, result);
+#endif
     }
     return hipGetLastError();
 }

@@ -203,6 +203,24 @@ int main(int argc, char **argv) {
                         st[10] / tot, st[11] / tot, st[12] / tot, st[13] / tot, st[14] / tot, st[15] / tot, tot / st[7]);
         }
     }
+    if (what == "fast") {  // -DLZ4HIP_TEAM_PROF builds: cycles per role and phase of the team kernel
+        typedef int (*prof_fn)(unsigned long long *);
+        if (prof_fn f = (prof_fn)dlsym(RTLD_DEFAULT, "lz4hip_debug_team_prof")) {
+            unsigned long long st[16];
+            if (f(st) == 0 && st[4]) {
+                const double w = (double)st[4];
+                fprintf(stderr,
+                        "{\"team_cycles_per_walker_window\":{\"walker\":{\"wait_window\":%.0f,\"records_stale\":%.0f,\"walk\":%.0f,"
+                        "\"puts_handover\":%.0f},\"producers_per_own_window\":{\"wait\":%.0f,\"fill\":%.0f,\"phase_a\":%.0f},"
+                        "\"encoder_per_record\":{\"wait\":%.0f,\"encode\":%.0f}},\"walker_windows\":%llu,\"stale_windows\":%llu,"
+                        "\"records\":%llu,\"produced_windows\":%llu,\"rare_steps\":%llu,\"bytes_per_window\":%.1f}\n",
+                        st[0] / w, st[1] / w, st[2] / w, st[3] / w, st[8] / (double)(st[11] ? st[11] : 1),
+                        st[9] / (double)(st[11] ? st[11] : 1), st[10] / (double)(st[11] ? st[11] : 1),
+                        st[12] / (double)(st[14] ? st[14] : 1), st[13] / (double)(st[14] ? st[14] : 1), st[4], st[5],
+                        st[6], st[11], st[7], (double)n * reps / w);
+            }
+        }
+    }
     if (what == "hc") {  // -DLZ4HIP_HC_PROF builds of the library export per-phase cycle sums
         typedef int (*prof_fn)(unsigned long long *);
         if (prof_fn f = (prof_fn)dlsym(RTLD_DEFAULT, "lz4hip_debug_hc_prof")) {

@@ -12,7 +12,7 @@ TD=$R/tests/golden/testdata
 cd /tmp
 pmc() {  # pmc NAME "COUNTERS" args...
   name=$1; ctr=$2; shift 2
-  timeout -s KILL 240 rocprofv3 --kernel-include-regex "lz4hip" --pmc $ctr --output-format csv -d $O/pmc_$name -o p -- $B $TD "$@" > $O/pmc_$name.log 2>&1 || return 1
+  timeout -s KILL ${PMC_KILL:-240} rocprofv3 --kernel-include-regex "lz4hip" --pmc $ctr --output-format csv -d $O/pmc_$name -o p -- $B $TD "$@" > $O/pmc_$name.log 2>&1 || return 1
 }
 stats() {  # stats NAME args...
   name=$1; shift
@@ -47,11 +47,19 @@ if [ $WHAT = all ] || [ $WHAT = hc ]; then
   timeout -k 10 200 $B $TD binary 4 20 hc 1 131072 > $O/hc_binary.json || exit 1
   timeout -k 10 200 $B $TD text 4 20 hc 1 131072 > $O/hc_text.json || exit 1
   cat $O/hc_*.json
-  stats hc binary 1 20 hc 1 131072 || exit 1
-  N=$((1<<30))
-  pmc hc_mem "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" binary 1 20 hc 1 131072 || exit 1
-  pmc hc_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" binary 1 20 hc 1 131072 || exit 1
-  for p in hc_mem hc_sq; do echo "# pass $p: prof_bench binary 1 GiB, 1 MiB blocks, HC depth 131072, 1 rep"; python3 $R/tools/prof/pmc_rows.py $O/pmc_$p $N; done > $O/pmc_hc_rows.txt
+  # at cfg4's own size (4 GiB = 4096 blocks of 1 MiB, one wave each: 4 waves per SIMD), not at 1 GiB
+  PMC_KILL=600
+  stats hc binary 4 20 hc 1 131072 || exit 1
+  stats hc_text text 4 20 hc 1 131072 || exit 1
+  N=$((4<<30))
+  pmc hc_mem "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" binary 4 20 hc 1 131072 || exit 1
+  pmc hc_ea "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" binary 4 20 hc 1 131072 || exit 1
+  pmc hc_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" binary 4 20 hc 1 131072 || exit 1
+  pmc hct_mem "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" text 4 20 hc 1 131072 || exit 1
+  pmc hct_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" text 4 20 hc 1 131072 || exit 1
+  { for p in hc_mem hc_ea hc_sq; do echo "# pass $p: prof_bench binary 4 GiB, 1 MiB blocks (cfg4), HC depth 131072, 1 rep"; python3 $R/tools/prof/pmc_rows.py $O/pmc_$p $N; done
+    for p in hct_mem hct_sq; do echo "# pass $p: prof_bench text 4 GiB, 1 MiB blocks, HC depth 131072, 1 rep"; python3 $R/tools/prof/pmc_rows.py $O/pmc_$p $N; done; } > $O/pmc_hc_rows.txt
+  PMC_KILL=240
 fi
 if [ $WHAT = all ] || [ $WHAT = lds ]; then
   # LDS bank conflicts and wave occupancy of the three kernels (north star: "rocprof counters for ... LDS bank
