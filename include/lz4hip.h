@@ -102,8 +102,11 @@ size_t lz4hip_compress_bound(size_t n);
  * as called per block by FrameDataBlock.Compress, lz4stream/block.go:232-234. */
 /* d_workspace (optional): lz4hip_fast_workspace_bytes(n_blocks) bytes, 16-byte
  * aligned.  With a workspace the hash tables live in global memory (L2 /
- * Infinity-Cache resident) and many wavefronts per CU run; with NULL each table
- * lives in LDS, one block per CU.  The output bytes are the same.  The last 256
+ * Infinity-Cache resident) and many wavefronts per CU run, one per block; with NULL --
+ * or with at most 512 blocks, for which lz4hip_fast_workspace_bytes returns 0 -- each
+ * table lives in LDS and a team of six wavefronts works on every block, one block per CU
+ * (the regime of lz4.CompressBlock and of a Writer with its default options).  The
+ * output bytes are the same.  The last 256
  * bytes of a workspace of the full size hold the block counter of the dynamic
  * schedule (waves take their next block when they finish one); a workspace that
  * is a whole number of 128 KiB tables still works, with a round-robin deal. */

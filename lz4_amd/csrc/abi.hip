@@ -133,7 +133,7 @@ int lz4hip_shutdown(void) {
 size_t lz4hip_compress_bound(size_t n) { return n + n / 255 + 16; }
 
 size_t lz4hip_fast_workspace_bytes(size_t n_blocks) {
-    if (n_blocks < kFastGlobalMinBlocks) return 0;  // LDS-table kernel, no workspace needed
+    if (n_blocks < kFastGlobalMinBlocks) return 0;  // team kernel (table in LDS), no workspace needed
     const size_t want = 3072;  // 12 waves per CU on 256 CUs: the measured plateau
     return (n_blocks < want ? n_blocks : want) * kFastSlotBytes + kFastCounterBytes;
 }
@@ -156,8 +156,9 @@ int lz4hip_compress_fast_blocks(const void *d_src, size_t n, uint32_t block_size
     uint32_t *next_block = fast_ws_split(d_workspace, workspace_bytes, slots);
     if (d_workspace && (!aligned16(d_workspace) || slots == 0))
         return fail(LZ4HIP_ERR_ARG, "workspace unaligned or smaller than one table");
-    // Few blocks: one block per CU with the table in LDS finishes each block sooner.
-    // Many blocks: global tables and many waves per CU give the higher throughput.
+    // Few blocks (up to two per CU): a team of waves per block with the table in LDS finishes
+    // each block sooner.  Many blocks: global tables and many waves per CU give the higher
+    // throughput (crossover measured at 512 blocks: profiles/r3_fast_team.txt).
     if (nb < kFastGlobalMinBlocks) slots = 0;
     HIPCHK(launch_fast((const uint8_t *)d_src, n, block_size, nb, dst_mode, 0, (uint8_t *)d_dst,
                        dst_stride, d_result, (uint16_t *)d_workspace, slots, next_block,

@@ -43,7 +43,10 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 constexpr size_t kFastSlots = 8192;             // resident waves of the global-table Fast kernel
 constexpr size_t kFastSlotBytes = 65536 * 2;    // one u16 table
 constexpr size_t kFastCounterBytes = 256;       // tail of the Fast workspace: the block counter of the dynamic schedule
-constexpr size_t kFastGlobalMinBlocks = 257;    // up to one block per CU the LDS-table kernel is used
+#ifndef LZ4HIP_FAST_GLOBAL_MIN
+#define LZ4HIP_FAST_GLOBAL_MIN 513
+#endif
+constexpr size_t kFastGlobalMinBlocks = LZ4HIP_FAST_GLOBAL_MIN;    // below: the team kernel (table in LDS, one block per CU)
 constexpr size_t kHcSlots = 4096;               // resident workgroups of the HC kernel
 constexpr uint32_t kLegacyBlock = 8u << 20;     // blocks.go:11, frame.go:49
 constexpr size_t kMaxSingleBlock = 1u << 30;    // int32 positions inside a block

@@ -1,25 +1,28 @@
-// fast3.hip -- window-parallel Fast LZ4 compressor, generation 3.
+// fast.hip -- window-parallel Fast LZ4 compressor, one wavefront per block, hash tables in a
+// global-memory workspace (k_fast_gtab).  Launches with few blocks take fast_team.hip instead.
 //
 // Same parse and bytes as (*Compressor).CompressBlock
-// (internal/lz4block/block.go:105-295).  Phase A is fast2's (64 lanes hash, gather
-// the table, verify, pre-extend).  What changes is the serial part:
+// (internal/lz4block/block.go:105-295).  Per 64-position window:
 //
-//   Phase B, the wave-uniform walk, now only decides WHERE matches are: per match
-//   it costs a handful of scalar operations (find the lane, read its forward
-//   length, move si/anchor, note the puts).  It records the anchor into the match
-//   lane (v_writelane) instead of emitting anything.
+//   Phase A: 64 lanes hash their position, gather the table, derive the candidate by get()'s
+//   rule, verify 4 bytes and pre-extend (16 B forward, 8 B backward).
+//
+//   Phase B, the wave-uniform walk, only decides WHERE matches are.  Its common steps --
+//   three clean misses, a match whose lane answer is final -- are hand-written scalar code
+//   (fast_common.h walk_common_steps: ~28 SALU instructions per step; the compiler's version
+//   of the same C++ was ~70 with a dozen branches, and the walk is the serial part of the
+//   kernel); steps whose probes may depend on a put of this window, or whose match needs
+//   cooperative extension, are resolved here in the reference's order.  Nothing is emitted
+//   and no per-lane state is written during the walk: a match's anchor is the end of the
+//   match before it.
 //
 //   Phase C, at window close, encodes ALL sequences of the window at once: every
-//   match lane derives literal/match lengths (backward extension clamped by the
-//   recorded anchor, block.go:170-177), a wave scan of the encoded sizes gives each
+//   match lane derives literal/match lengths (backward extension clamped by its
+//   anchor, block.go:170-177), a wave scan of the encoded sizes gives each
 //   sequence its place in dst, one comparison decides the dst-capacity outcome
 //   (every check of block.go:196-245 guards a byte inside the sequence's extent,
 //   so they all pass iff the extents fit), and the lanes write token, lengths,
 //   literals and offset themselves.
-//
-// The scalar unit was the busiest part of generation 2 (14.6 SALU instructions
-// per input byte, profiles/r1_v1_pmc_fast2_summary.txt); this moves the per-
-// sequence work to the vector lanes.
 #include "fast_common.h"
 
 namespace lz4hip {
@@ -52,9 +55,7 @@ static_assert(kSrcHist >= 8 && kSrcHist + 2 * kSrcReach <= kSrcBuf, "a refill mu
 // request).  0: the global table is zeroed at every block start instead and every valid lane
 // gathers -- 3.5 KiB of LDS per wave, so twice as many waves fit a CU.
 constexpr bool kBitmap = LZ4HIP_FAST_BITMAP;
-#ifndef LZ4HIP_FAST_TEAM
-#define LZ4HIP_FAST_TEAM 1   // launches without a workspace (few blocks): a team of waves per block (fast_team.hip)
-#endif
+
 constexpr bool kGateExt = LZ4HIP_FAST_GATE;     // extension loads only behind a verified candidate
 constexpr bool kCandLds = LZ4HIP_FAST_CANDLDS;  // candidates inside the LDS source buffer are read there
 
@@ -77,7 +78,7 @@ constexpr bool kCandLds = LZ4HIP_FAST_CANDLDS;  // candidates inside the LDS sou
 #define FAST_TIME(i)
 #endif
 
-template <bool kGlobal, typename TablePtr>
+template <typename TablePtr>
 __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const int n,
                                            uint8_t *__restrict__ d, const int dlen,
                                            TablePtr table, uint32_t *tag, uint8_t *sbuf,
@@ -91,20 +92,16 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
     const int bound = (int)compress_bound32((uint32_t)n);
     const bool not_compressible = dlen < bound;  // block.go:110
     {  // reset(): block.go:94,107
-        if (kGlobal && !kBitmap) {
+        if (!kBitmap) {
             typedef uint4 __attribute__((may_alias)) uint4_a;
             uint4_a *t4 = (uint4_a *)(table);
             for (int k = lane; k < (1 << 16) * 2 / 16; k += kWave) t4[k] = make_uint4(0, 0, 0, 0);
             __threadfence();
-        } else if (kGlobal) {
+        } else {
             // the reference's own scheme: clear the in-use bitmap (8 KiB, here in LDS), not the
             // table.  A get() of an unused slot is answered from the bitmap -- table value 0,
             // block.go:74-79 -- without touching memory, and the table is never zeroed.
             for (int k = lane; k < kInUseWords; k += kWave) inuse[k] = 0u;
-        } else {  // LDS table: an all-zero table is the cleared-bitmap state
-            typedef uint4 __attribute__((may_alias)) uint4_a;
-            uint4_a *t4 = (uint4_a *)(table);
-            for (int k = lane; k < (1 << 16) * 2 / 16; k += kWave) t4[k] = make_uint4(0, 0, 0, 0);
         }
         for (int k = lane; k < kTagN; k += kWave) tag[k] = 0xFFFFFFFFu;
     }
@@ -151,11 +148,9 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
         if (valid) __builtin_memcpy(&x, sl + p, 8);
         const uint32_t h = hash6(x);
         uint32_t tv = 0;
-        if (kGlobal) {
+        {
             const bool used = valid && (!kBitmap || ((inuse[h >> 5] >> (h & 31)) & 1u));
-            if (used) tv = tab_load<kGlobal>(table, h);
-        } else if (valid) {
-            tv = tab_load<kGlobal>(table, h);
+            if (used) tv = tab_load(table, h);
         }
         const uint32_t slot = h & (kTagN - 1);
         if (valid) atomicMin(&tag[slot], (uint32_t)lane);
@@ -211,7 +206,7 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
             __builtin_memcpy(&qb, sl + p - 8, 8);
         }
         FAST_STAT(7, 1);
-        FAST_STAT(1, __builtin_popcountll(ballot(kGlobal && kBitmap ? (valid && ((inuse[h >> 5] >> (h & 31)) & 1u)) : valid)));
+        FAST_STAT(1, __builtin_popcountll(ballot(kBitmap ? (valid && ((inuse[h >> 5] >> (h & 31)) & 1u)) : valid)));
         FAST_STAT(2, __builtin_popcountll(ballot(offok)));
         FAST_STAT(3, __builtin_popcountll(ballot(f0ok)));
         FAST_STAT(4, __builtin_popcountll(ballot(f1ok)));
@@ -252,130 +247,105 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
             }
         }
         const uint64_t M = ballot(m4), CM = ballot(cflag);
-        const uint64_t SLOW = ballot(fmore || bmore);  // matches that may need more extension
-        const uint64_t ATT = M | CM;                   // lanes that need a look during the walk
+        const uint64_t RARE = CM | ballot(fmore || bmore);  // probes that need more than a lookup
+        const uint64_t ATT = M | CM;                        // lanes that need a look during the walk
         const uint16_t pos16 = (uint16_t)p;
-        int anch = 0;          // anchor recorded into the match lanes by the walk
+        const uint32_t flv = (uint32_t)fmore | ((uint32_t)bmore << 1);
+        const int anchor_in = anchor;  // a match's anchor is the end of the match before it, else this
         uint64_t FOUND = 0;    // match lanes of this window
         uint64_t P = pending ? 1ull : 0ull;  // lanes put() since the snapshot; lane 0 = put(si-2)
         pending = false;
 
-        // The next window will gather the table for positions wbase+64.. (unless a long
-        // match jumps over them): touch those lines now, so that the walk below hides
-        // their trip from HBM and the next gather finds them in L2.
 #ifdef LZ4HIP_FAST_STATS
         if (ballot(m4) != 0x5555555555555557ull) FAST_TIME(12);  // (uses the candidate words)
 #endif
         // ================= Phase B: where are the matches =================
+        // The common steps (three clean misses; a match whose lane answer is final) run as
+        // hand-written scalar code (fast_common.h); it hands the steps that need more back.
         for (;;) {
             si = (int)rfl((uint32_t)si);
             anchor = (int)rfl((uint32_t)anchor);
-            P = ((uint64_t)rfl((uint32_t)(P >> 32)) << 32) | rfl((uint32_t)P);
-            FOUND = ((uint64_t)rfl((uint32_t)(FOUND >> 32)) << 32) | rfl((uint32_t)FOUND);
+            const int st = walk_common_steps(si, anchor, P, FOUND, wbase, sn, ATT, RARE, mendv);
+            if (st == 0) break;
+            if (st == 2) {  // block.go:250-252
+                finished = true;
+                break;
+            }
+            // ---- rare: a probe may depend on a put of this window, or the match
+            // needs cooperative extension.  Resolve in the reference's order. ----
             const int a = si - wbase;
-            if (a > 61 || si >= sn) break;
-            const uint32_t att3 = (uint32_t)(ATT >> a) & 7u;
-            if (att3 == 0) {
-                // three failed probes, three puts (:136-137,155), skip (:159)
-                const int d0 = si + 2 - anchor;
-                if (d0 <= 64 && si + 64 < sn) {
-                    const uint64_t pat = 0x7777777777777777ull << a;  // probed lanes a+4k+{0,1,2}
-                    const uint64_t hot = ATT & pat;
-                    const int kmax = ((61 - a) >> 2) + 1;
-                    int k = hot ? (__builtin_ctzll(hot) - a) >> 2 : kmax;  // clean steps (>= 1)
-                    if (k > kmax) k = kmax;
-                    const int e = a + 4 * k;
-                    P |= e >= 64 ? pat : (pat & ((1ull << e) - 1));
-                    si += 4 * k;
-                } else {
-                    P |= 7ull << a;
-                    si += 4 + (d0 >> kAdaptSkipLog);
+            int j = -1, dep_l = -1;
+#pragma unroll
+            for (int t = 0; t < 3 && j < 0; ++t) {
+                const int b = a + t;
+                // probes 0,1 see the puts before this step; probe 2 also put(si), put(si+1)
+                const uint64_t vis = t == 2 ? (P | (3ull << a)) : P;
+                bool hit = (M >> b) & 1;
+                int dl = -1;
+                if ((CM >> b) & 1) {
+                    const uint64_t E = ballot(h == rdlane(h, b)) & vis;
+                    if (E) {
+                        dl = 63 - __builtin_clzll(E);  // the latest put with my hash
+                        hit = rdlane((uint32_t)x, b) == rdlane((uint32_t)x, dl);
+                    }
                 }
+                if (hit) {
+                    j = t;
+                    dep_l = dl;
+                }
+            }
+            if (j < 0) {
+                P |= 7ull << a;
+                si += 4 + ((si + 2 - anchor) >> kAdaptSkipLog);
                 continue;
             }
-            int f;  // match lane
-            if ((((CM | SLOW) >> a) & 7u) == 0) {
-                // ---- common case: snapshot answers exact, extension complete ----
-                const int j = __builtin_ctz(att3);
-                f = a + j;
-                P |= (j == 2 ? 7ull : 3ull) << a;
-                anch = wrlane(anch, anchor, f);
-                si = (int)rdlane((uint32_t)mendv, f);
+            const int f = a + j;  // match lane
+            P |= (j == 2 ? 7ull : 3ull) << a;
+            const int found = si + j;
+            const int l0 = found - anchor;
+            int offset, back, mend;
+            if (dep_l >= 0) {
+                offset = f - dep_l;
+                const int mref = found - offset;
+                const int maxb = l0 < mref ? l0 : mref;
+                back = ext_backward(s, found, mref, 0, maxb, lane);
+                mend = ext_forward(s, found + kMinMatch, offset, sn, lane);
             } else {
-                // ---- rare: a probe may depend on a put of this window, or the match
-                // needs cooperative extension.  Resolve in the reference's order. ----
-                int j = -1, dep_l = -1;
-#pragma unroll
-                for (int t = 0; t < 3 && j < 0; ++t) {
-                    const int b = a + t;
-                    // probes 0,1 see the puts before this step; probe 2 also put(si), put(si+1)
-                    const uint64_t vis = t == 2 ? (P | (3ull << a)) : P;
-                    bool hit = (M >> b) & 1;
-                    int dl = -1;
-                    if ((CM >> b) & 1) {
-                        const uint64_t E = ballot(h == rdlane(h, b)) & vis;
-                        if (E) {
-                            dl = 63 - __builtin_clzll(E);  // the latest put with my hash
-                            hit = rdlane((uint32_t)x, b) == rdlane((uint32_t)x, dl);
-                        }
-                    }
-                    if (hit) {
-                        j = t;
-                        dep_l = dl;
-                    }
-                }
-                if (j < 0) {
-                    P |= 7ull << a;
-                    si += 4 + ((si + 2 - anchor) >> kAdaptSkipLog);
-                    continue;
-                }
-                f = a + j;
-                P |= (j == 2 ? 7ull : 3ull) << a;
-                const int found = si + j;
-                const int l0 = found - anchor;
-                int offset, back, mend;
-                if (dep_l >= 0) {
-                    offset = f - dep_l;
-                    const int mref = found - offset;
-                    const int maxb = l0 < mref ? l0 : mref;
-                    back = ext_backward(s, found, mref, 0, maxb, lane);
-                    mend = ext_forward(s, found + kMinMatch, offset, sn, lane);
-                } else {
-                    offset = (int)rdlane((uint32_t)offv, f);
-                    const int mref = found - offset;
-                    const int maxb = l0 < mref ? l0 : mref;
-                    const int bw = (int)rdlane((uint32_t)backv, f);
-                    back = bw < maxb ? bw : maxb;
-                    mend = (int)rdlane((uint32_t)mendv, f);
-                    const uint32_t fl = rdlane((uint32_t)fmore | ((uint32_t)bmore << 1), f);
-                    if ((fl & 2u) && maxb > bw) back = ext_backward(s, found, mref, bw, maxb, lane);
-                    if (fl & 1u) mend = ext_forward(s, mend, offset, sn, lane);
-                }
-                offv = wrlane(offv, offset, f);
-                backv = wrlane(backv, back, f);
-                mendv = wrlane(mendv, mend, f);
-                anch = wrlane(anch, anchor, f);
-                si = mend;
+                offset = (int)rdlane((uint32_t)offv, f);
+                const int mref = found - offset;
+                const int maxb = l0 < mref ? l0 : mref;
+                const int bw = (int)rdlane((uint32_t)backv, f);
+                back = bw < maxb ? bw : maxb;
+                mend = (int)rdlane((uint32_t)mendv, f);
+                const uint32_t fl = rdlane(flv, f);
+                if ((fl & 2u) && maxb > bw) back = ext_backward(s, found, mref, bw, maxb, lane);
+                if (fl & 1u) mend = ext_forward(s, mend, offset, sn, lane);
             }
+            offv = wrlane(offv, offset, f);
+            backv = wrlane(backv, back, f);
+            mendv = wrlane(mendv, mend, f);
+            si = mend;
             FOUND |= 1ull << f;
             anchor = si;
             if (si >= sn) {  // block.go:250-252
                 finished = true;
                 break;
             }
-            // put(hash(si-2), si-2): block.go:254-255
-            const int q = si - 2 - wbase;
-            if (q <= 63)
-                P |= 1ull << q;
-            else
-                pending = true;  // lane 0 of the next window
+            const int q = si - 2 - wbase;  // put(hash(si-2), si-2): block.go:254-255
+            if (q <= 63) P |= 1ull << q;
         }
+        // a match that ended the window leaves its put(si-2) to the next one (its lane 0)
+        pending = !finished && anchor == si && si - 2 - wbase > 63;
 
         FAST_TIME(13);
         // ================= Phase C: encode every sequence of the window =================
         if (FOUND) {
             const bool mine = (FOUND >> lane) & 1;
-            // block.go:166-182 with the recorded anchor
+            // the anchor of a match: the end of the match before it in the window (block.go:249)
+            const uint64_t below = FOUND & ((1ull << lane) - 1);
+            const int prev_end = __shfl(mendv, below ? 63 - __builtin_clzll(below) : 0);
+            const int anch = below ? prev_end : anchor_in;
+            // block.go:166-182 with that anchor
             const int l0 = p - anch;
             const int mref = p - offv;
             int back = backv;
@@ -448,7 +418,7 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
                 if (lane == l) table[h] = pos16;
             }
             __asm__ volatile("" ::: "memory");
-            if (kGlobal && kBitmap && ((P >> lane) & 1)) atomicOr(&inuse[h >> 5], 1u << (h & 31));
+            if (kBitmap && ((P >> lane) & 1)) atomicOr(&inuse[h >> 5], 1u << (h & 31));
             __asm__ volatile("" ::: "memory");
         }
         FAST_TIME(15);
@@ -487,27 +457,6 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
     return ret;
 }
 
-// Table in LDS: one wave (= one workgroup) per block, one block per CU.
-__global__ __launch_bounds__(64) void k_fast_lds(const uint8_t *__restrict__ src, size_t n_total,
-                                                  uint32_t block_size, int dst_mode,
-                                                  uint32_t dst_len_x, uint8_t *__restrict__ dst,
-                                                  size_t dst_stride,
-                                                  int32_t *__restrict__ result) {
-    __shared__ uint16_t table[1 << 16];
-    __shared__ uint32_t tag[kTagN];
-    __shared__ __attribute__((aligned(16))) uint8_t sbuf[kSrcBuf];
-    __shared__ __attribute__((aligned(16))) uint8_t obuf[kOutBuf + 16];
-    const int lane = lane_id();
-    const size_t b = blockIdx.x;
-    const size_t start = b * (size_t)block_size;
-    const size_t left = n_total > start ? n_total - start : 0;
-    const int n = (int)(left < block_size ? left : block_size);
-    const int r = fast_block<false>(src + start, n, dst + b * dst_stride,
-                                     block_dlen2(dst_mode, n, dst_len_x), table, tag, sbuf, obuf,
-                                     nullptr, lane);
-    if (lane == 0) result[b] = r;
-}
-
 // Table in a global-memory slot per resident wave; many waves per CU.
 __global__ __launch_bounds__(64) void k_fast_gtab(const uint8_t *__restrict__ src, size_t n_total,
                                                    uint32_t block_size, size_t nb, int dst_mode,
@@ -538,7 +487,7 @@ __global__ __launch_bounds__(64) void k_fast_gtab(const uint8_t *__restrict__ sr
         const size_t start = b * (size_t)block_size;
         const size_t left = n_total > start ? n_total - start : 0;
         const int n = (int)(left < block_size ? left : block_size);
-        const int r = fast_block<true>(src + start, n, dst + b * dst_stride,
+        const int r = fast_block(src + start, n, dst + b * dst_stride,
                                        block_dlen2(dst_mode, n, dst_len_x), table, tag, sbuf, obuf,
                                        inuse, lane,
                                        reinterpret_cast<unsigned long long *>(next_block));
@@ -564,13 +513,8 @@ hipError_t launch_fast(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int
         }
         hipLaunchKernelGGL(k_fast_gtab, dim3((unsigned)grid), dim3(kWave), 0, st, src, n, bs, nb,
                            dst_mode, dst_len_x, dst, dst_stride, result, ws, next_block);
-    } else {
-#if LZ4HIP_FAST_TEAM
+    } else {  // few blocks: a team of waves per block, table in LDS (fast_team.hip)
         return launch_fast_team(src, n, bs, nb, dst_mode, dst_len_x, dst, dst_stride, result, st);
-#else
-        hipLaunchKernelGGL(k_fast_lds, dim3((unsigned)nb), dim3(kWave), 0, st, src, n, bs,
-                           dst_mode, dst_len_x, dst, dst_stride, result);
-#endif
     }
     return hipGetLastError();
 }

@@ -56,10 +56,8 @@ __device__ __forceinline__ int ext_forward(const uint8_t *s, int si, int offset,
 // bypasses the CU's vector L1 (sc1, served by L2): the wave's own recent 2-byte
 // stores are written through to L2, but an L1-resident copy of the line is not
 // guaranteed to be refreshed before a later gather hits it.
-template <bool kGlobal>
 __device__ __forceinline__ uint32_t tab_load(const uint16_t *t, uint32_t h) {
-    if (kGlobal) return __hip_atomic_load(t + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return t[h];
+    return __hip_atomic_load(t + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Lane `l` of `old` takes the wave-uniform value `v` (v_cmp + v_cndmask: the VOP3
@@ -123,6 +121,10 @@ __device__ __forceinline__ int len_tail_size(int len) {  // bytes after the toke
     return len >= 0xF ? 1 + (len - 0xF) / 255 : 0;
 }
 
+__device__ __forceinline__ uint64_t rfl64(uint64_t v) {
+    return ((uint64_t)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v);
+}
+
 // ---------------------------------------------------------------------------------------
 // The common steps of the walk (phase B) as hand-written scalar code.
 //
@@ -143,6 +145,13 @@ __device__ __forceinline__ int walk_common_steps(int &si, int &anchor, uint64_t 
     int st, t0, t1, t2, t3;
     uint64_t u0, u1;
     const uint64_t pat7 = 0x7777777777777777ull;
+    // (wave-uniform by construction; the scalar operands below need the compiler to know it)
+    si = (int)rfl((uint32_t)si);
+    anchor = (int)rfl((uint32_t)anchor);
+    P = rfl64(P);
+    FOUND = rfl64(FOUND);
+    const int base_s = (int)rfl((uint32_t)base), sn_s = (int)rfl((uint32_t)sn);
+    const uint64_t att_s = rfl64(ATT), rare_s = rfl64(RARE);
     __asm__ volatile(
         "Ltop%=:\n\t"
         "s_sub_i32 %[t0], %[si], %[base]\n\t"          // a
@@ -224,7 +233,7 @@ __device__ __forceinline__ int walk_common_steps(int &si, int &anchor, uint64_t 
         "Lout%=:\n\t"
         : [si] "+s"(si), [anchor] "+s"(anchor), [P] "+s"(P), [F] "+s"(FOUND), [st] "=&s"(st),
           [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [u0] "=&s"(u0), [u1] "=&s"(u1)
-        : [base] "s"(base), [sn] "s"(sn), [att] "s"(ATT), [rare] "s"(RARE), [mend] "v"(mendv),
+        : [base] "s"(base_s), [sn] "s"(sn_s), [att] "s"(att_s), [rare] "s"(rare_s), [mend] "v"(mendv),
           [pat7] "s"(pat7)
         : "scc", "memory");
     return st;

@@ -330,7 +330,7 @@ __device__ __forceinline__ void team_producer(const uint8_t *__restrict__ s, con
             while (cm) {
                 const int b = __builtin_ctzll(cm);
                 const uint64_t E = ballot(valid && h == rdlane(h, b));  // every lane with b's hash
-                if ((E >> lane) & (E & ((1ull << lane) - 1) ? 1 : 0)) cflag = true;  // all but the first of them
+                if (((E >> lane) & 1) && (E & ((1ull << lane) - 1)) != 0) cflag = true;  // all but the first of them
                 cm &= ~E;
             }
         }

@@ -28,7 +28,7 @@ _ws_cache = {}
 
 def fast_workspace(nb, device):
     """Cached hash-table workspace of the Fast compressor (None when the batch is small
-    enough for the LDS-table kernel).  One per (device, stream): the workspace holds the
+    enough for the team kernel, whose tables live in LDS).  One per (device, stream): the workspace holds the
     tables and the block counter of a launch, so two launches that may overlap -- different
     streams -- must not share one.  A workspace that is outgrown is kept alive until the
     stream it served has drained (record_stream), never freed under a running kernel."""

@@ -389,9 +389,92 @@ def test_xxh32_stream_update_chain(T, oracle):
     assert (int(dev.xxh32_stream(src).item()) & 0xFFFFFFFF) == oracle.ChecksumZero(data)
 
 
+def _adversarial(rng, n, text):
+    """Runs, short periods, tiny alphabets, noisy text, sorted and random bytes, long runs of
+    varying length, text with a far repeat: what makes the walk jump over windows, re-evaluate
+    stale lanes, forward in-window puts and extend matches cooperatively."""
+    parts, left = [], n
+    while left > 0:
+        m = min(left, int(rng.integers(1, 1 << 17)))
+        k = int(rng.integers(0, 8))
+        if k == 0:
+            a = np.full(m, int(rng.integers(0, 256)), dtype=np.uint8)
+        elif k == 1:
+            q = rng.integers(0, 256, int(rng.integers(1, 300)), dtype=np.uint8)
+            a = np.tile(q, m // q.size + 1)[:m]
+        elif k == 2:
+            a = rng.integers(0, int(rng.integers(2, 6)), m, dtype=np.uint8)
+        elif k == 3:
+            a = text[int(rng.integers(0, text.size - m)):][:m].copy()
+            hit = rng.random(m) < rng.choice([0.001, 0.01, 0.1])
+            a[hit] = rng.integers(0, 256, int(hit.sum()), dtype=np.uint8)
+        elif k == 4:
+            a = np.sort(rng.integers(0, 256, m, dtype=np.uint8))
+        elif k == 5:
+            a = rng.integers(0, 256, m, dtype=np.uint8)
+        elif k == 6:
+            a, i = np.empty(m, dtype=np.uint8), 0
+            while i < m:
+                run = int(rng.integers(1, 5000))
+                a[i:i + run] = int(rng.integers(0, 4))
+                i += run
+        else:
+            a = text[int(rng.integers(0, text.size - m)):][:m].copy()
+            if m > 5000:
+                j = int(rng.integers(0, m - 3000))
+                a[-2000:] = a[j:j + 2000]
+        parts.append(a)
+        left -= m
+    return np.concatenate(parts)
+
+
+@pytest.mark.parametrize("bs,nb,seed", [(1 << 22, 5, 1), (1 << 20, 20, 2), (1 << 18, 70, 3), (1 << 16, 300, 4)])
+def test_fast_team_kernel_few_large_blocks(T, oracle, bs, nb, seed):
+    """Up to 512 blocks take the team kernel (fast_team.hip: six waves per block, table in LDS).
+    Corpus kinds at the reference Writer's default block size and adversarial data at every
+    block size, ragged last block, against the oracle byte for byte."""
+    from lz4_amd import corpus, device as dev
+    assert dev.fast_workspace(nb + 1, T.device("cuda", 0)) is None       # no workspace: the team kernel
+    rng = np.random.default_rng(seed)
+    text = corpus.generate("text", 0, 1 << 20)
+    data = _adversarial(rng, nb * bs + int(rng.integers(1, bs)), text)
+    _check_blocks(T, oracle, data, bs)
+    if bs == 1 << 22:
+        for kind in ("mixed", "binary", "text"):
+            _check_blocks(T, oracle, corpus.generate(kind, 3 << 20, 3 * bs + 12345), bs)
+
+
+def test_fast_team_kernel_short_dst_and_tiny_blocks(T, oracle):
+    """The encoder wave's dst-capacity verdict (block.go:196-245) ends the whole team: bound-sized
+    and len(src)-sized dst on incompressible and barely compressible blocks, and blocks too short
+    for any window (sn <= 0)."""
+    from lz4_amd import _lib, corpus, device as dev
+    rng = np.random.default_rng(11)
+    bs = 1 << 16
+    blocks = [rng.integers(0, 256, bs, dtype=np.uint8),                        # incompressible
+              np.concatenate([rng.integers(0, 256, bs - 64, dtype=np.uint8), np.zeros(64, np.uint8)]),
+              corpus.generate("text", 99, bs),
+              np.concatenate([np.zeros(40, np.uint8), rng.integers(0, 256, bs - 40, dtype=np.uint8)])]
+    data = np.concatenate(blocks + [rng.integers(0, 256, 9, dtype=np.uint8)])  # 9-byte last block
+    src = _dev(T, data)
+    for mode in (_lib.DST_FRAME, _lib.DST_BOUND):
+        comp, res = dev.compress_blocks(src, bs, 0, dst_mode=mode)
+        res_h, comp_h = res.cpu().numpy(), comp.cpu().numpy()
+        for b in range(res_h.shape[0]):
+            blk = data[b * bs:(b + 1) * bs]
+            dl = blk.size if mode == _lib.DST_FRAME else oracle.CompressBlockBound(blk.size)
+            try:
+                k, pl = oracle.CompressBlock(blk, dl)
+            except oracle.ErrInvalidSourceShortBuffer:
+                k, pl = -1, b""
+            assert int(res_h[b]) == k, (mode, b, int(res_h[b]), k)
+            if k > 0:
+                assert comp_h[b, :k].tobytes() == pl, (mode, b)
+
+
 def test_fast_many_blocks_global_table_kernel(T, oracle):
-    """>= 257 blocks select the global-table kernel (many waves per CU); its bytes
-    must equal the LDS-table kernel's and the oracle's."""
+    """>= 513 blocks select the global-table kernel (one wave per block, many waves per CU); its
+    bytes must equal the team kernel's and the oracle's."""
     from lz4_amd import corpus, device as dev
     bs = 1 << 16
     data = corpus.generate("mixed", 123, 1500 * bs + 999)
@@ -409,7 +492,7 @@ def test_fast_block_schedule(T, oracle, tail):
     and again on a second launch that reuses the workspace (the counter is re-armed)."""
     from lz4_amd import corpus, device as dev
     bs = 1 << 16
-    data = corpus.generate("mixed", 55, 300 * bs + 17, )
+    data = corpus.generate("mixed", 55, 500 * bs + 17, )      # (>= 513 blocks: the global-table kernel)
     data = np.concatenate([data, corpus.generate("text", 9, 90 * bs + 5)])
     src = _dev(T, data)
     ws = T.empty(37 * 131072 + tail, dtype=T.uint8, device="cuda")

@@ -1,4 +1,5 @@
-"""One-off wide fuzz of the batched Fast compressor (global-table kernel) against the oracle:
+"""One-off wide fuzz of the batched Fast compressor (global-table kernel from 513 blocks up, team
+kernel below) against the oracle:
     python tools/fuzz_fast.py [SEED]
 Blocks of adversarial synthetic data (runs, short periods, tiny alphabets, sparse noise on
 text, sorted bytes) at 64 KiB and 256 KiB block sizes, frame and bound dst modes."""
@@ -38,7 +39,7 @@ def piece(n):
     j = int(rng.integers(0, max(n - 3000, 1))); a[-2000:] = a[j:j + 2000] if n > 5000 else a[-2000:]
     return a
 
-for bs, nb in ((1 << 16, 600), (1 << 18, 300)):
+for bs, nb in ((1 << 16, 700), (1 << 18, 600), (1 << 16, 400), (1 << 18, 200), (1 << 20, 48), (1 << 22, 12)):
     parts = []
     for b in range(nb):
         cuts = sorted(rng.integers(1, bs, int(rng.integers(0, 3))).tolist()) + [bs]
