@@ -43,7 +43,7 @@ constexpr int kTeamStride = 60;
 #define LZ4HIP_TEAM_PRODUCERS 4
 #endif
 #ifndef LZ4HIP_TEAM_LEAD
-#define LZ4HIP_TEAM_LEAD 4
+#define LZ4HIP_TEAM_LEAD 3
 #endif
 constexpr int kProducers = LZ4HIP_TEAM_PRODUCERS;   // producer p takes the windows w = p (mod kProducers)
 constexpr int kTeamThreads = (2 + kProducers) * kWave;
@@ -72,10 +72,7 @@ struct TeamShared {
     uint32_t done;            // the walker has finished the block
     uint32_t abort;           // the encoder ran out of dst
     int32_t fill_lo, fill_hi; // the ring holds s[max(fill_lo, fill_hi - 7168), fill_hi)
-    uint32_t e_found[kRingE][2];
-    int32_t e_wbase[kRingE];
-    int32_t e_anchor[kRingE];
-    uint32_t e_last[kRingE];
+    uint32_t e_hdr[kRingE][8];  // a record's scalars: FOUND lo, hi, window base, entry anchor, last
     uint32_t a_rec[kRingA][3][kWave];
     uint32_t e_rec[kRingE][3][kWave];
 };
@@ -555,14 +552,14 @@ __device__ __forceinline__ void team_walker(const uint8_t *__restrict__ s, const
         }
         // ---- the window's matches go to the encoder ----
         if (FOUND) {
-            if (lane == 0) {
-                S->e_found[es][0] = (uint32_t)FOUND;
-                S->e_found[es][1] = (uint32_t)(FOUND >> 32);
-                S->e_wbase[es] = wbase;
-                S->e_anchor[es] = anchor_in;
-                S->e_last[es] = 0;
+            {   // the record's scalars, one word per lane, in one store
+                const uint32_t v = lane == 0 ? (uint32_t)FOUND : lane == 1 ? (uint32_t)(FOUND >> 32)
+                                 : lane == 2 ? (uint32_t)wbase : lane == 3 ? (uint32_t)anchor_in : 0u;
+                if (lane < 5) S->e_hdr[es][lane] = v;
             }
-            LDS_DRAIN();
+            // (LDS operations of a wave are performed in order: the record is complete when
+            // its sequence word is)
+            __asm__ volatile("" ::: "memory");
             if (lane == 0) lds_st(&S->e_seq[es], k + 1);
             k++;
             TP_N(6, 1);
@@ -574,8 +571,8 @@ __device__ __forceinline__ void team_walker(const uint8_t *__restrict__ s, const
         if (!aborted) {
             const int es = (int)(k & (kRingE - 1));
             if (lane == 0) {
-                S->e_anchor[es] = (int)rfl((uint32_t)anchor);
-                S->e_last[es] = 1;
+                S->e_hdr[es][3] = (uint32_t)(int)rfl((uint32_t)anchor);
+                S->e_hdr[es][4] = 1u;
             }
             LDS_DRAIN();
             if (lane == 0) lds_st(&S->e_seq[es], k + 1);
@@ -613,14 +610,15 @@ __device__ __forceinline__ int team_encoder(const uint8_t *__restrict__ s, const
         TP_T(12);
         TP_N(14, 1);
         __asm__ volatile("" ::: "memory");
-        const uint32_t last = lds_ld(&S->e_last[es]);
+        const uint32_t hdr = S->e_hdr[es][lane & 7];
+        const uint32_t last = rdlane(hdr, 4);
         if (last) {
-            anchor = (int)lds_ld((uint32_t *)&S->e_anchor[es]);
+            anchor = (int)rdlane(hdr, 3);
             break;
         }
-        const uint64_t FOUND = ((uint64_t)lds_ld(&S->e_found[es][1]) << 32) | lds_ld(&S->e_found[es][0]);
-        const int wbase = (int)lds_ld((uint32_t *)&S->e_wbase[es]);
-        const int anchor_in = (int)lds_ld((uint32_t *)&S->e_anchor[es]);
+        const uint64_t FOUND = ((uint64_t)rdlane(hdr, 1) << 32) | rdlane(hdr, 0);
+        const int wbase = (int)rdlane(hdr, 2);
+        const int anchor_in = (int)rdlane(hdr, 3);
         const int mendv = (int)S->e_rec[es][0][lane];
         const int offv = (int)S->e_rec[es][1][lane], backv = (int)S->e_rec[es][2][lane];
         LDS_DRAIN();

@@ -10,7 +10,7 @@ from lz4_amd import corpus, device as dev, _lib
 from oracle import pyoracle as orc
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 5)
-text = corpus.generate("text", 0, 1 << 20)
+text = corpus.generate("text", 0, 9 << 20)
 
 def piece(n):
     k = int(rng.integers(0, 8))
