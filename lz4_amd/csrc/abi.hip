@@ -134,7 +134,10 @@ size_t lz4hip_compress_bound(size_t n) { return n + n / 255 + 16; }
 
 size_t lz4hip_fast_workspace_bytes(size_t n_blocks) {
     if (n_blocks < kFastGlobalMinBlocks) return 0;  // team kernel (table in LDS), no workspace needed
-    const size_t want = 3072;  // 12 waves per CU on 256 CUs: the measured plateau
+    // 12 waves per CU on 256 CUs: the measured plateau.  3329..4096 blocks: a table
+    // for every block, so that all of them run at once (16 waves per CU, compact LDS layout)
+    // instead of a full round and a third of one.
+    const size_t want = n_blocks > 3328 && n_blocks <= 4096 ? n_blocks : 3072;
     return (n_blocks < want ? n_blocks : want) * kFastSlotBytes + kFastCounterBytes;
 }
 

@@ -33,9 +33,21 @@ namespace lz4hip {
 #ifndef LZ4HIP_OUTBUF
 #define LZ4HIP_OUTBUF 512
 #endif
-constexpr int kSrcBuf = LZ4HIP_SRCBUF;   // LDS bytes of buffered source per wave
 constexpr int kSrcReach = 84;   // phase A reads s[wbase-8, wbase+84)
-constexpr int kOutBuf = LZ4HIP_OUTBUF;   // LDS bytes in which a window's sequences are assembled (0: none)
+// LDS per wave besides the 8 KiB in-use bitmap: tag slots (u32 each), bytes of buffered source,
+// bytes in which a window's sequences are assembled.  Two sizes are built: the standard one
+// (11.8 KiB per wave: 13 waves per CU) and a compact one of exactly 10 KiB, which admits 16
+// waves per CU.  The compact one is 4 % slower wave for wave (more refills, more false tag
+// collisions) and only pays when it saves a round: launches of 3329..4096 blocks -- cfg5's
+// 16 GiB share in 4 MiB blocks is 4096 -- run all blocks at once instead of 1.33 rounds of
+// 3072 (526 -> 466 ms; profiles/r3_fast_gtab_wave_sweep.txt).  Same bytes either way.
+constexpr size_t kFastStdResident = 3328;  // 13 waves per CU x 256 CUs
+struct FastStd {
+    static constexpr int kTag = kTagN, kSrc = LZ4HIP_SRCBUF, kOut = LZ4HIP_OUTBUF;
+};
+struct FastCompact {
+    static constexpr int kTag = 256, kSrc = 512, kOut = 496;
+};
 constexpr int kInUseWords = (1 << 16) / 32;  // block.go:57: inUse [1<<16/32]uint32
 #ifndef LZ4HIP_FAST_GATE
 #define LZ4HIP_FAST_GATE 0
@@ -47,7 +59,8 @@ constexpr int kInUseWords = (1 << 16) / 32;  // block.go:57: inUse [1<<16/32]uin
 #define LZ4HIP_FAST_HIST 8
 #endif
 constexpr int kSrcHist = LZ4HIP_FAST_HIST;      // source bytes behind the window kept at a refill (>= 8)
-static_assert(kSrcHist >= 8 && kSrcHist + 2 * kSrcReach <= kSrcBuf, "a refill must cover the window");
+static_assert(kSrcHist >= 8 && kSrcHist + 2 * kSrcReach <= FastStd::kSrc && kSrcHist + 2 * kSrcReach <= FastCompact::kSrc,
+              "a refill must cover the window");
 #ifndef LZ4HIP_FAST_BITMAP
 #define LZ4HIP_FAST_BITMAP 1
 #endif
@@ -78,7 +91,7 @@ constexpr bool kCandLds = LZ4HIP_FAST_CANDLDS;  // candidates inside the LDS sou
 #define FAST_TIME(i)
 #endif
 
-template <typename TablePtr>
+template <typename Cfg, typename TablePtr>
 __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const int n,
                                            uint8_t *__restrict__ d, const int dlen,
                                            TablePtr table, uint32_t *tag, uint8_t *sbuf,
@@ -89,6 +102,7 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
     stat[9] = (unsigned long long)n;
     unsigned long long last_t = __builtin_readcyclecounter();
 #endif
+    constexpr int kTagN = Cfg::kTag, kSrcBuf = Cfg::kSrc, kOutBuf = Cfg::kOut;
     const int bound = (int)compress_bound32((uint32_t)n);
     const bool not_compressible = dlen < bound;  // block.go:110
     {  // reset(): block.go:94,107
@@ -458,6 +472,7 @@ __device__ __forceinline__ int fast_block(const uint8_t *__restrict__ s, const i
 }
 
 // Table in a global-memory slot per resident wave; many waves per CU.
+template <typename Cfg>
 __global__ __launch_bounds__(64) void k_fast_gtab(const uint8_t *__restrict__ src, size_t n_total,
                                                    uint32_t block_size, size_t nb, int dst_mode,
                                                    uint32_t dst_len_x, uint8_t *__restrict__ dst,
@@ -465,9 +480,9 @@ __global__ __launch_bounds__(64) void k_fast_gtab(const uint8_t *__restrict__ sr
                                                    int32_t *__restrict__ result,
                                                    uint16_t *__restrict__ ws,
                                                    uint32_t *__restrict__ next_block) {
-    __shared__ uint32_t tag[kTagN];
-    __shared__ __attribute__((aligned(16))) uint8_t sbuf[kSrcBuf];
-    __shared__ __attribute__((aligned(16))) uint8_t obuf[kOutBuf + 16];
+    __shared__ uint32_t tag[Cfg::kTag];
+    __shared__ __attribute__((aligned(16))) uint8_t sbuf[Cfg::kSrc];
+    __shared__ __attribute__((aligned(16))) uint8_t obuf[Cfg::kOut + 16];
     __shared__ uint32_t inuse[kBitmap ? kInUseWords : 1];
     const int lane = lane_id();
     uint16_t *table = ws + (size_t)blockIdx.x * (1 << 16);
@@ -487,7 +502,7 @@ __global__ __launch_bounds__(64) void k_fast_gtab(const uint8_t *__restrict__ sr
         const size_t start = b * (size_t)block_size;
         const size_t left = n_total > start ? n_total - start : 0;
         const int n = (int)(left < block_size ? left : block_size);
-        const int r = fast_block(src + start, n, dst + b * dst_stride,
+        const int r = fast_block<Cfg>(src + start, n, dst + b * dst_stride,
                                        block_dlen2(dst_mode, n, dst_len_x), table, tag, sbuf, obuf,
                                        inuse, lane,
                                        reinterpret_cast<unsigned long long *>(next_block));
@@ -505,14 +520,22 @@ hipError_t launch_fast(const uint8_t *src, size_t n, uint32_t bs, size_t nb, int
                         uint16_t *ws, size_t slots, uint32_t *next_block, hipStream_t st) {
     if (nb == 0) return hipSuccess;
     if (ws && slots) {
-        const size_t grid = nb < slots ? nb : slots;
+        size_t grid = nb < slots ? nb : slots;
+        // More than 13 waves per CU only pay when they save a round (every block gets a wave at
+        // 16 per CU); with rounds to go anyway the standard layout at its 12-per-CU plateau wins.
+        if (grid > kFastStdResident && (nb > grid || grid > 4096)) grid = 3072;
         if (grid == nb) next_block = nullptr;  // every block has a wave of its own
         if (next_block) {
             const hipError_t e = hipMemsetAsync(next_block, 0, sizeof(uint32_t), st);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(k_fast_gtab, dim3((unsigned)grid), dim3(kWave), 0, st, src, n, bs, nb,
-                           dst_mode, dst_len_x, dst, dst_stride, result, ws, next_block);
+        // more waves than 13 per CU can be resident only with the compact LDS layout
+        if (grid > kFastStdResident)
+            hipLaunchKernelGGL(k_fast_gtab<FastCompact>, dim3((unsigned)grid), dim3(kWave), 0, st, src, n, bs,
+                               nb, dst_mode, dst_len_x, dst, dst_stride, result, ws, next_block);
+        else
+            hipLaunchKernelGGL(k_fast_gtab<FastStd>, dim3((unsigned)grid), dim3(kWave), 0, st, src, n, bs, nb,
+                               dst_mode, dst_len_x, dst, dst_stride, result, ws, next_block);
     } else {  // few blocks: a team of waves per block, table in LDS (fast_team.hip)
         return launch_fast_team(src, n, bs, nb, dst_mode, dst_len_x, dst, dst_stride, result, st);
     }

@@ -485,6 +485,18 @@ def test_fast_many_blocks_global_table_kernel(T, oracle):
     _check_blocks(T, oracle, data, bs)
 
 
+def test_fast_compact_layout_3329_to_4096_blocks(T, oracle):
+    """3329..4096 blocks get a table each and run at once, 16 waves per CU, with the compact LDS
+    layout of the kernel (fast.hip FastCompact: fewer tag slots, shorter source buffer): same bytes."""
+    from lz4_amd import _lib, corpus, device as dev
+    bs = 1 << 16
+    nb = 3500
+    assert _lib.load().lz4hip_fast_workspace_bytes(nb) == nb * 131072 + 256
+    data = np.concatenate([corpus.generate("mixed", 31, 1800 * bs), corpus.generate("text", 77, 900 * bs),
+                           corpus.generate("binary", 5, 800 * bs - 4321)])
+    _check_blocks(T, oracle, data, bs)
+
+
 @pytest.mark.parametrize("tail", [256, 0])
 def test_fast_block_schedule(T, oracle, tail):
     """More blocks than workspace tables: with the 256-byte counter tail the waves take
