@@ -74,6 +74,46 @@ def test_argument_validation_without_gpu():
     assert lib.lz4hip_hc_workspace_bytes(1) == 65536 * 4 + 65536 * 64 * 2 + 256
 
 
+def test_xxh32_host_update_chain_without_gpu(oracle):
+    """lz4hip_xxh32_host_update is XXHZero.Write / Sum32 on the calling thread (no GPU): pieces
+    chained through the 6-word state equal the oracle's one-shot checksum and its streaming one,
+    and a handed-over totalLen at the 2^32 boundary takes Sum32's short-input branch as the
+    reference does (xxh32zero.go:113-118, SURVEY trap T6)."""
+    import ctypes as C
+    from lz4_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    data = rng.integers(0, 256, 100_003, dtype=np.uint8)
+    for cuts in ([0, 100_003], [0, 16, 100_003], [0, 4096, 65536, 99_984, 100_003], [0, 0, 48, 100_003]):
+        st = np.zeros(6, dtype=np.uint32)
+        dg = C.c_uint32()
+        for i in range(len(cuts) - 1):
+            a, b = cuts[i], cuts[i + 1]
+            last = i == len(cuts) - 2
+            piece = data[a:b]
+            rc = lib.lz4hip_xxh32_host_update(piece.ctypes.data if piece.size else None, piece.size,
+                                              st.ctypes.data, int(i == 0), int(last),
+                                              C.addressof(dg) if last else None)
+            assert rc == 0, lib.lz4hip_last_error()
+        assert dg.value == oracle.ChecksumZero(data), cuts
+    # a non-final piece must be a stripe multiple
+    st = np.zeros(6, dtype=np.uint32)
+    assert lib.lz4hip_xxh32_host_update(data.ctypes.data, 17, st.ctypes.data, 1, 0, None) == _lib.ERR_ARG
+    # T6: state handed over with totalLen = 2^32 - 32, then 32 + 5 bytes: uint32(totalLen) = 5 < 16
+    h = oracle.XXHZero()
+    h.Write(data[:64])
+    h.set_total_len((1 << 32) - 32)
+    st = np.zeros(6, dtype=np.uint32)
+    st[:4] = np.frombuffer(h._s[0:16].tobytes(), dtype=np.uint32)
+    st[4], st[5] = ((1 << 32) - 32) & 0xFFFFFFFF, 0
+    tail = data[64:64 + 37]
+    h.Write(tail)
+    dg = C.c_uint32()
+    assert lib.lz4hip_xxh32_host_update(tail.ctypes.data, 37, st.ctypes.data, 0, 1, C.addressof(dg)) == 0
+    assert dg.value == h.Sum32()
+    assert (int(st[4]) | int(st[5]) << 32) == (1 << 32) + 5
+
+
 def test_bad_arguments_are_not_the_codec_verdict():
     """-1 from the single-block calls means ErrInvalidSourceShortBuffer, which the frame
     step turns into "store raw" (lz4stream/block.go:238-245): a call that fails for another
