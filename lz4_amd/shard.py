@@ -94,7 +94,10 @@ class DeviceOps:
         the hash alone, not download + hash."""
         if self.checksum_on != "host" or not src.is_cuda or n == 0:
             return None
-        return _StageAhead(src, n)
+        try:
+            return _StageAhead(src, n)
+        except RuntimeError:      # no pinned memory to be had: the turn brings the bytes down itself
+            return None
 
     def xxh32_update_staged(self, staged, src, n, state, first, final):
         """xxh32_update over a shard whose first staged.m bytes are in host memory."""
@@ -137,10 +140,12 @@ _pinned = {}        # device index -> pinned uint8 staging tensor, kept between 
 
 
 def reserve_staging(n, device=None):
-    """Pinned host memory for stage_ahead, allocated (page-locking 16 GiB takes seconds) outside
-    the caller's timed region; capped at LZ4_SHARD_STAGE_GIB (default 16) GiB per process."""
+    """Pinned host memory for stage_ahead, allocated (page-locking gigabytes takes seconds) outside
+    the caller's timed region; capped at LZ4_SHARD_STAGE_GIB (default 4) GiB per process -- eight
+    ranks of a node pin 32 GiB between them; what lies beyond the cap comes down piecewise in the
+    rank's turn, as without staging."""
     import os
-    cap = int(float(os.environ.get("LZ4_SHARD_STAGE_GIB", "16")) * (1 << 30)) & ~15
+    cap = int(float(os.environ.get("LZ4_SHARD_STAGE_GIB", "4")) * (1 << 30)) & ~15
     m = min(n, cap) & ~15 if n > cap else n
     key = torch.cuda.current_device() if device is None else device.index
     buf = _pinned.get(key)

@@ -28,6 +28,8 @@ def _run(world, job, tmp_path):
     jf.write_text(json.dumps(job))
     port = 23000 + (os.getpid() * 7 + world * 131 + len(job["writes"]) + 17 * len(job["reads"])) % 4000
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if world == 3:      # a staging cap below the shard sizes: part of a shard staged, the rest streamed
+        env["LZ4_SHARD_STAGE_GIB"] = "0.0005"
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shard_gpu_worker.py"), str(r), str(world),
                                str(port), str(jf), str(tmp_path)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
