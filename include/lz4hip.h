@@ -109,7 +109,11 @@ size_t lz4hip_compress_bound(size_t n);
  * output bytes are the same.  The last 256
  * bytes of a workspace of the full size hold the block counter of the dynamic
  * schedule (waves take their next block when they finish one); a workspace that
- * is a whole number of 128 KiB tables still works, with a round-robin deal. */
+ * is a whole number of 128 KiB tables still works, with a round-robin deal.
+ * lz4hip_fast_workspace_bytes asks for 3072 tables (12 resident waves per CU, the measured
+ * plateau) for most launches and for one table per block for 3329..4096 blocks, which then all
+ * run at once (16 waves per CU with a compact LDS layout of the same kernel) instead of one
+ * round and a third of one. */
 size_t lz4hip_fast_workspace_bytes(size_t n_blocks);
 int lz4hip_compress_fast_blocks(const void *d_src, size_t n, uint32_t block_size, int dst_mode,
                                 void *d_dst, size_t dst_stride, int32_t *d_result,
