@@ -29,6 +29,12 @@ static_assert(kHcLinks == kWave, "one link per lane");
 #ifndef LZ4HIP_HC_GATE
 #define LZ4HIP_HC_GATE 8  // held match length from which the one-load gate precedes the prefix compare
 #endif
+#ifndef LZ4HIP_HC_FRONT
+#define LZ4HIP_HC_FRONT 1  // misses in a row from which the lock-step miss front runs (0: never)
+#endif
+#ifndef LZ4HIP_HC_FRONT_PEN
+#define LZ4HIP_HC_FRONT_PEN 63  // most searches the front sits out after confirming nothing
+#endif
 constexpr int kHcSlotWords = (1 << 16) + (1 << 16) * kHcLinks / 2;
 
 // Links of a position inserted behind `head` (distance d0 > 0, inside the window), given
@@ -61,10 +67,10 @@ __device__ __forceinline__ void hc_insert(uint32_t *hash_table, uint16_t *chain_
 // first stride; the few long ones decide how long the wave waits, so after the first stride
 // the compare runs 32 bytes per round trip (four strides in flight) while 32 more bytes are
 // inside lim -- the same first differing byte is found either way.
-__device__ __forceinline__ int hc_prefix_len(const uint8_t *s, int next, int si, int lim) {
+__device__ __forceinline__ int hc_prefix_len(const uint8_t *s, int next, int si, int lim, uint64_t w_si) {
     int ml = 0;
     {
-        const uint64_t x = ld64(s + next) ^ ld64(s + si);
+        const uint64_t x = ld64(s + next) ^ w_si;  // w_si: the 8 bytes at si (every lane would load the same)
         if (x != 0) return __builtin_ctzll(x) >> 3;
         ml = 8;
     }
@@ -139,8 +145,11 @@ struct HcPre {
 constexpr int kRowStride = kHcLinks + 8;  // u16 units: 144-byte rows spread the lanes' 16-byte accesses over the banks
 
 __device__ __forceinline__ uint32_t hc_shift(uint32_t x, uint32_t d0) {  // one link of the head, seen from d0 further on
-    const uint32_t t = x + d0;
-    return (x != 0 && t < (uint32_t)kWinSize) ? t : 0u;
+    // (x != 0 && x + d0 < kWinSize) ? x + d0 : 0, without condition masks (64 of these per lane and
+    // round: as compares they fill the scalar registers with masks): x == 0 counts as 65536
+    const uint32_t y = x - 1u;
+    const uint32_t t = (y < 0xFFFFu ? y : 0xFFFFu) + d0 + 1u;  // < 2^17
+    return t & ((t >> 16) - 1u);
 }
 
 __device__ __forceinline__ void hc_insert_round(uint32_t *hash_table, uint16_t *chain_table,
@@ -323,8 +332,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
         pre.w = 0;
         pre.h = pre.l = 0;
         pre.head = 0;
-        uint64_t w_last = 0;  // the 8 source bytes read last, at w_pos
-        int w_pos = -8;
+        // the source bytes read last: w_avail (8 or 16) bytes at w_pos, fetched by two lanes
+        uint64_t w_last = 0, w_next = 0;
+        int w_pos = -16, w_avail = 0;
+        int miss_run = 0;          // searches that missed since the last match
+        int fr_pen = 0, fr_skip = 0;  // the miss front backs off where it confirms nothing (text)
         // A sequence's literals (up to 64) are read at emission and stored at the end of the next
         // search, one byte per lane: a wave's loads return in order, so they have arrived with
         // that search's own loads, and the emission itself waits for nothing.
@@ -337,17 +349,136 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             }
         };
         while (si < sn) {
+#if LZ4HIP_HC_FRONT > 0
+            // ---- The miss front.  77 % of the searches of kernel-image data find nothing, and each
+            // is a chain of dependent fetches (head, head's entry, candidate bytes) with nothing
+            // else for the wave to do.  Inside a run of misses the next positions are known
+            // (:386-389), so eight searches are taken in lock-step, eight lanes each: the fetches of
+            // one level fly together (a wave's loads return in order, so only loads of one level
+            // overlap well).  The front only CONFIRMS misses: a search whose chain has at most 16
+            // candidates inside the window, none of them equal to si over 4 bytes, is finished --
+            // entry and head stored as hc_insert would -- and the leading run of such searches is
+            // committed.  The first search that has a match, a longer chain, the hash of an
+            // earlier search of the step (that one's insertion moves its head) or of a waiting
+            // position goes to the full search below, with its lines already in the caches.
+            if (miss_run >= LZ4HIP_HC_FRONT && fr_skip == 0) {
+                typedef uint4 __attribute__((may_alias)) uint4_a;
+                int lq = lane;  // opaque: what hangs off g and t is not kept in registers across the searches
+                __asm__ volatile("" : "+v"(lq));
+                const int g = lq >> 3, t = lq & 7;
+                int P = si, q = si;
+#pragma unroll
+                for (int i = 1; i <= 8; i++) {
+                    q += 1 + ((q - anchor) >> kAdaptSkipLog);
+                    if (g >= i) P = q;
+                }
+                bool bad = P >= sn;
+                uint64_t w = 0;
+                if (!bad) w = ld64(s + P);
+                const uint32_t hq = hash4((uint32_t)w);
+                {
+                    const uint32_t ho = (uint32_t)__shfl((int)hq, t * 8);  // the hash of group t
+                    if (t < g && ho == hq) bad = true;
+                }
+                if (pd_n) {
+                    if (P - __builtin_amdgcn_readlane(pd_pos, 0) >= (kWinSize >> 1)) bad = true;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)hq, 8 * i);
+                        if (ballot(lane < pd_n && pd_h == hi) && g == i) bad = true;
+                    }
+                }
+                int head = 0;
+                if (!bad) head = (int)hash_table[hq];
+                const bool inw = !bad && head > 0 && P - head < kWinSize;
+                uint4 e = make_uint4(0, 0, 0, 0);  // links 8t .. 8t+7 of the head's entry
+                uint32_t c0 = 0, c1 = 0;           // links t-1 and t+7: candidates t and t+8
+                if (inw) {
+                    const uint16_t *ent = chain_table + (size_t)(head & kWinMask) * kHcLinks;
+                    e = *(const uint4_a *)(ent + 8 * t);
+                    if (t > 0) c0 = ent[t - 1];
+                    c1 = ent[t + 7];
+                }
+                const int cand0 = t == 0 ? head : head - (int)c0;
+                // (the walk looks at `depth` candidates at most: :347-356)
+                const bool v0 = inw && (uint32_t)t < depth && (t == 0 || (c0 != 0 && P - cand0 < kWinSize));
+                const int cand1 = head - (int)c1;
+                const bool v1 = inw && (uint32_t)t + 8u < depth && c1 != 0 && P - cand1 < kWinSize;
+                uint32_t x0 = 1, x1 = 1;
+                if (v0) x0 = ld32(s + cand0) ^ (uint32_t)w;
+                if (v1) x1 = ld32(s + cand1) ^ (uint32_t)w;
+                // a 17th candidate (link 15) inside the window: not for the front
+                if (inw && t == 1 && depth > 16u) {
+                    const uint32_t l15 = e.w >> 16;
+                    if (l15 != 0 && P - (head - (int)l15) < kWinSize) bad = true;
+                }
+                const uint32_t prev7 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(e.w >> 16), 0x111, 0xF, 0xF, false);
+                if (x0 == 0 || x1 == 0) bad = true;  // four equal bytes: a match
+                const uint64_t B = ballot(bad);
+                const int m = B ? (int)(__builtin_ctzll(B) >> 3) : 8;
+                if (g < m) {
+                    uint4 o = make_uint4(0, 0, 0, 0);
+                    if (inw) {
+                        const uint32_t d0 = (uint32_t)(P - head);
+                        o.x = (t == 0 ? d0 : hc_shift(prev7, d0)) | (hc_shift(e.x & 0xFFFFu, d0) << 16);
+                        o.y = hc_shift(e.x >> 16, d0) | (hc_shift(e.y & 0xFFFFu, d0) << 16);
+                        o.z = hc_shift(e.y >> 16, d0) | (hc_shift(e.z & 0xFFFFu, d0) << 16);
+                        o.w = hc_shift(e.z >> 16, d0) | (hc_shift(e.w & 0xFFFFu, d0) << 16);
+                    }
+                    *(uint4_a *)(chain_table + (size_t)(P & kWinMask) * kHcLinks + 8 * t) = o;
+                    if (t == 0) hash_table[hq] = (uint32_t)P;
+                }
+                HC_N(15, m);
+                HC_T(7);
+                if (m == 0) {
+                    fr_pen = 2 * fr_pen + 1;
+                    if (fr_pen > LZ4HIP_HC_FRONT_PEN) fr_pen = LZ4HIP_HC_FRONT_PEN;
+                    fr_skip = fr_pen;
+                } else if (m == 1) {
+                    fr_skip = fr_pen;
+                } else {
+                    fr_pen >>= 1;
+                }
+                if (m == 8) {
+                    si = q;
+                    continue;
+                }
+                si = __builtin_amdgcn_readlane(P, 8 * m);
+                if (si >= sn) break;
+                // the bytes at si are here already
+                w_last = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, 8 * m) |
+                         ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), 8 * m) << 32);
+                w_pos = si;
+                w_avail = 8;
+            }
+            if (fr_skip > 0) fr_skip--;
+#endif
             // fetched beside the last match's insertion
             const bool ridden = pre.ok && pre.pos == si;
             pre.ok = false;
             // after a miss the search moves on by a byte or two: the 4 bytes it needs are in the 8
             // already read (one round trip less in front of the table lookup)
             const int w_sh = si - w_pos;
-            const bool held = w_sh >= 0 && w_sh <= 4;
-            const uint64_t w = ridden ? pre.w : held ? w_last >> (8 * w_sh) : ld64(s + si);
-            if (ridden || !held) {
+            const bool held = w_sh >= 0 && w_sh + 8 <= w_avail;
+            uint64_t w;
+            if (ridden) {
+                w = pre.w;
                 w_last = w;
                 w_pos = si;
+                w_avail = 8;
+            } else if (held) {
+                w = w_sh == 0 ? w_last : w_sh == 8 ? w_next : (w_last >> (8 * w_sh)) | (w_next << (64 - 8 * w_sh));
+            } else {
+                // lanes 0 and 1 fetch 8 bytes each (the second 8 only where the block has them)
+                w_avail = si + 16 <= n ? 16 : 8;
+                uint64_t t = 0;
+                if (lane * 8 < w_avail) t = ld64(s + si + lane * 8);
+                w_last = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)t, 0) |
+                         ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(t >> 32), 0) << 32);
+                w_next = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)t, 1) |
+                         ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(t >> 32), 1) << 32);
+                w_pos = si;
+                w = w_last;
             }
             uint32_t match = (uint32_t)w;
             const uint32_t h = ridden ? pre.h : hash4(match);
@@ -370,7 +501,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             uint32_t my_link = 0;  // lane j: link j of si's own chain entry (from the first batch)
             {
                 const int lim = sn - si;
-                int next = ridden ? pre.head : (int)hash_table[h];
+                int next = pre.head;
+                if (!ridden) {  // one lane fetches, the wave takes it from there
+                    uint32_t t = 0;
+                    if (lane == 0) t = hash_table[h];
+                    next = (int)rfl(t);
+                }
                 uint32_t tries = depth;
                 // A prefix length never exceeds lim rounded up to 8 (:363-372) and only a
                 // strictly longer candidate replaces the winner (:373), so the walk can
@@ -381,6 +517,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 uint32_t l = 0;
                 if (in_window(next)) l = ridden ? pre.l : chain_table[(size_t)(next & kWinMask) * kHcLinks + lane];
                 bool first = true;
+                uint64_t gate_w = 0;
                 while (tries > 0 && in_window(next) && m_len < ml_max) {
 #ifdef LZ4HIP_HC_PROF
                     nbatch++;
@@ -420,8 +557,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                         // so it must agree with si at index m_len -- and a chain's later
                         // members mostly do not.  One load decides that instead of a compare
                         // over m_len bytes (several dependent round trips the wave waits for).
-                        const bool gate = m_len < LZ4HIP_HC_GATE || ld64(s + mine + m_len - 7) == ld64(s + si + m_len - 7);
-                        if (gate) ml = hc_prefix_len(s, mine, si, lim);
+                        const bool gate = m_len < LZ4HIP_HC_GATE || ld64(s + mine + m_len - 7) == gate_w;
+                        if (gate) ml = hc_prefix_len(s, mine, si, lim, w);
                     }
                     // winner: max ml, ties to the earliest chain entry (lowest lane); only a strictly
                     // longer candidate replaces the held one (:373-379), and on a long walk most
@@ -431,6 +568,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                         const int best = wave_max(key);
                         m_len = best >> 6;
                         offset = si - __builtin_amdgcn_readlane(mine, 63 - (best & 63));
+                        // si's side of the gate: it changes with the held length only
+                        if (m_len >= LZ4HIP_HC_GATE) gate_w = ld64(s + si + m_len - 7);
                     }
                 }
             }
@@ -451,8 +590,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
 
             if (m_len == 0) {  // :386-389
                 si += 1 + ((si - anchor) >> kAdaptSkipLog);
+                miss_run++;
                 continue;
             }
+            miss_run = 0;
 
             {  // insert every position covered by the match: :394-405
                 int p = si + 1;
