@@ -35,6 +35,21 @@ static_assert(kHcLinks == kWave, "one link per lane");
 #ifndef LZ4HIP_HC_FRONT_PEN
 #define LZ4HIP_HC_FRONT_PEN 63  // most searches the front sits out after confirming nothing
 #endif
+// experiment switch: which store acknowledgements the wave waits for (1: none after a search's
+// stores, 2: none after an insertion round)
+#ifndef LZ4HIP_HC_NOSYNC
+#define LZ4HIP_HC_NOSYNC 0
+#endif
+#if LZ4HIP_HC_NOSYNC & 1
+#define HC_SYNC_SEARCH() __asm__ volatile("" ::: "memory")
+#else
+#define HC_SYNC_SEARCH() __syncthreads()
+#endif
+#if LZ4HIP_HC_NOSYNC & 2
+#define HC_SYNC_ROUND() __asm__ volatile("" ::: "memory")
+#else
+#define HC_SYNC_ROUND() __syncthreads()
+#endif
 constexpr int kHcSlotWords = (1 << 16) + (1 << 16) * kHcLinks / 2;
 
 // Links of a position inserted behind `head` (distance d0 > 0, inside the window), given
@@ -234,7 +249,7 @@ __device__ __forceinline__ void hc_insert_round(uint32_t *hash_table, uint16_t *
         }
     }
     if (act && !later) hash_table[hh] = (uint32_t)p;
-    __syncthreads();  // the next round gathers what this one stored, and reuses the rows
+    HC_SYNC_ROUND();  // the next round gathers what this one stored, and reuses the rows
 }
 
 __device__ __forceinline__ void hc_insert_run(uint32_t *hash_table, uint16_t *chain_table,
@@ -254,6 +269,9 @@ __device__ __forceinline__ void hc_insert_run(uint32_t *hash_table, uint16_t *ch
 // [0..3] searches by batches walked (none, one, 2-8, more), [4] waiting-position bookkeeping and
 // the per-search store, [5] insertion rounds, [6] emission, [7] set-up and tail; counts: [8..11]
 // searches of those four kinds, [12] batches, [13] matches, [14] insertion rounds.
+#ifdef LZ4HIP_HC_PROF2  // experiment marks (LZ4HIP_PROF_RAW=1 prints the slots): see HC_U below
+#define LZ4HIP_HC_PROF
+#endif
 #ifdef LZ4HIP_HC_PROF
 __device__ unsigned long long g_hc_prof[16];
 #define HC_T(i)                                                       \
@@ -263,9 +281,32 @@ __device__ unsigned long long g_hc_prof[16];
         last_t = now_;                                                \
     } while (0)
 #define HC_N(i, v) prof[i] += (unsigned long long)(v)
+#ifdef LZ4HIP_HC_PROF2
+#undef HC_T
+#undef HC_N
+#define HC_T(i)
+#define HC_N(i, v)
+#define HC_U(i)                                                       \
+    do {                                                              \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        prof[i] += now_ - last_t;                                     \
+        last_t = now_;                                                \
+    } while (0)
+#define HC_M(i, v) prof[i] += (unsigned long long)(v)
+#define HC_V(i)                                               \
+    do {                                                      \
+        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        HC_U(i);                                              \
+    } while (0)
+#endif
 #else
 #define HC_T(i)
 #define HC_N(i, v)
+#endif
+#ifndef HC_U
+#define HC_U(i)
+#define HC_M(i, v)
+#define HC_V(i)
 #endif
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_hc_compress(const uint8_t *__restrict__ src,
@@ -332,9 +373,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
         pre.w = 0;
         pre.h = pre.l = 0;
         pre.head = 0;
-        // the source bytes read last: w_avail (8 or 16) bytes at w_pos, fetched by two lanes
-        uint64_t w_last = 0, w_next = 0;
-        int w_pos = -16, w_avail = 0;
+        // The source window: lane k holds the 8 bytes at wb + k (those that the block has), asked
+        // for when a match is known, at the position behind it, and not waited for: what the NEXT
+        // match needs of the source -- the 4-byte values of the positions it covers, the bytes of
+        // the search behind it -- is then in registers when that match is found (text: a match
+        // every 10 bytes; each of these was a round trip the wave sat out).
+        uint64_t W = 0;
+        int wb = -(1 << 30);
+        auto win_fetch = [&](int base) {
+            wb = base;
+            W = 0;
+            if (base + lane + 8 <= n) W = ld64(s + base + lane);
+        };
+        uint64_t w_nx = 0;  // the 8 bytes at w_nx_pos, taken from the window before it moved on
+        int w_nx_pos = -1;
+        auto rl64 = [&](uint64_t v, int l) {
+            return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l) |
+                   ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32);
+        };
         int miss_run = 0;          // searches that missed since the last match
         int fr_pen = 0, fr_skip = 0;  // the miss front backs off where it confirms nothing (text)
         // A sequence's literals (up to 64) are read at emission and stored at the end of the next
@@ -373,8 +429,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                     if (g >= i) P = q;
                 }
                 bool bad = P >= sn;
-                uint64_t w = 0;
-                if (!bad) w = ld64(s + P);
+                // the bytes at P from the window (fetched anew when the step leaves it)
+                if (ballot(!bad && (P - wb < 0 || P - wb >= kWave))) win_fetch(si);
+                const int wl = bad ? 0 : P - wb;
+                const uint64_t w = (uint64_t)(uint32_t)__shfl((int)(uint32_t)W, wl) |
+                                   ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(W >> 32), wl) << 32);
+                if (wl < 0 || wl >= kWave) bad = true;  // (a step of more than 9 bytes per search)
                 const uint32_t hq = hash4((uint32_t)w);
                 {
                     const uint32_t ho = (uint32_t)__shfl((int)hq, t * 8);  // the hash of group t
@@ -430,6 +490,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 }
                 HC_N(15, m);
                 HC_T(7);
+                HC_U(6);
                 if (m == 0) {
                     fr_pen = 2 * fr_pen + 1;
                     if (fr_pen > LZ4HIP_HC_FRONT_PEN) fr_pen = LZ4HIP_HC_FRONT_PEN;
@@ -445,40 +506,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 }
                 si = __builtin_amdgcn_readlane(P, 8 * m);
                 if (si >= sn) break;
-                // the bytes at si are here already
-                w_last = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, 8 * m) |
-                         ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), 8 * m) << 32);
-                w_pos = si;
-                w_avail = 8;
             }
             if (fr_skip > 0) fr_skip--;
 #endif
             // fetched beside the last match's insertion
             const bool ridden = pre.ok && pre.pos == si;
             pre.ok = false;
-            // after a miss the search moves on by a byte or two: the 4 bytes it needs are in the 8
-            // already read (one round trip less in front of the table lookup)
-            const int w_sh = si - w_pos;
-            const bool held = w_sh >= 0 && w_sh + 8 <= w_avail;
-            uint64_t w;
-            if (ridden) {
-                w = pre.w;
-                w_last = w;
-                w_pos = si;
-                w_avail = 8;
-            } else if (held) {
-                w = w_sh == 0 ? w_last : w_sh == 8 ? w_next : (w_last >> (8 * w_sh)) | (w_next << (64 - 8 * w_sh));
-            } else {
-                // lanes 0 and 1 fetch 8 bytes each (the second 8 only where the block has them)
-                w_avail = si + 16 <= n ? 16 : 8;
-                uint64_t t = 0;
-                if (lane * 8 < w_avail) t = ld64(s + si + lane * 8);
-                w_last = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)t, 0) |
-                         ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(t >> 32), 0) << 32);
-                w_next = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)t, 1) |
-                         ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(t >> 32), 1) << 32);
-                w_pos = si;
-                w = w_last;
+            // the bytes at si: kept from the last match, or in the window
+            uint64_t w = pre.w;
+            if (!ridden) {
+                w = w_nx;
+                if (w_nx_pos != si) {
+                    if (si - wb < 0 || si - wb >= kWave) win_fetch(si);
+                    w = rl64(W, si - wb);
+                }
             }
             uint32_t match = (uint32_t)w;
             const uint32_t h = ridden ? pre.h : hash4(match);
@@ -490,10 +531,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 none.w = 0;
                 none.h = none.l = 0;
                 none.head = 0;
+                HC_U(5);
                 hc_insert_round(hash_table, chain_table, s, pd_pos, pd_h, pd_n, lane, rows, none, false);
                 pd_n = 0;
+                HC_U(7);
+                HC_M(14, 1);
             }
             HC_T(4);
+            HC_U(5);
 #ifdef LZ4HIP_HC_PROF
             nbatch = 0;
 #endif
@@ -507,6 +552,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                     if (lane == 0) t = hash_table[h];
                     next = (int)rfl(t);
                 }
+                HC_V(9);
                 uint32_t tries = depth;
                 // A prefix length never exceeds lim rounded up to 8 (:363-372) and only a
                 // strictly longer candidate replaces the winner (:373), so the walk can
@@ -525,6 +571,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                     // one batch = cur itself (lane 0) and cur's links 0..62 (lanes 1..63);
                     // link 63 starts the next batch
                     const int cur = next;
+                    const bool first_batch_mark = first;
+                    if (first) HC_V(10);
                     // lane k: link k-1 (DPP wave_shr:1; lane 0 gets 0 and does not use it)
                     const uint32_t lk = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)l, 0x138, 0xF, 0xF, false);
                     const int mine = lane == 0 ? cur : cur - (int)lk;
@@ -560,6 +608,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                         const bool gate = m_len < LZ4HIP_HC_GATE || ld64(s + mine + m_len - 7) == gate_w;
                         if (gate) ml = hc_prefix_len(s, mine, si, lim, w);
                     }
+                    if (first_batch_mark) HC_V(11);
                     // winner: max ml, ties to the earliest chain entry (lowest lane); only a strictly
                     // longer candidate replaces the held one (:373-379), and on a long walk most
                     // batches have none: one ballot says so and the reduction is skipped
@@ -586,7 +635,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             put_literals();  // behind the search's own loads
             chain_table[(size_t)(si & kWinMask) * kHcLinks + lane] = (uint16_t)my_link;
             if (lane == 0) hash_table[h] = (uint32_t)si;
-            __syncthreads();
+            HC_U(0);
+            HC_SYNC_SEARCH();
+            HC_U(8);
+            HC_M(12, 1);
 
             if (m_len == 0) {  // :386-389
                 si += 1 + ((si - anchor) >> kAdaptSkipLog);
@@ -620,15 +672,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                         if (pd_n + cntp > kWave) {
                             // no room: the pending ones go in now, with the next search riding along
                             if (pre.pos >= 0) pre.w = ld64(s + pre.pos);
+                            HC_U(2);
                             hc_insert_round(hash_table, chain_table, s, pd_pos, pd_h, pd_n, lane, rows, pre,
                                             pre.pos >= 0);
                             pd_n = 0;
+                            HC_U(1);
+                            HC_M(15, 1);
                         } else {
                             pre.pos = -1;
                         }
-                        if (lane >= pd_n && lane < pd_n + cntp) {
-                            pd_pos = p + lane - pd_n;
-                            pd_h = hash4(ld32(s + pd_pos));
+                        {
+                            const bool mine_new = lane >= pd_n && lane < pd_n + cntp;
+                            const int np = p + lane - pd_n;
+                            const int wo = np - wb;  // from the window where it reaches
+                            const bool cov = wo >= 0 && wo < kWave;
+                            const uint32_t v = (uint32_t)__shfl((int)(uint32_t)W, cov ? wo : 0);
+                            if (mine_new) {
+                                pd_pos = np;
+                                pd_h = hash4(cov ? v : ld32(s + np));
+                            }
                         }
                         pd_n += cntp;
                         // a pending position with the next search's hash: that search will flush
@@ -656,16 +718,47 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                         hc_insert(hash_table, chain_table, hash4(match), p, lane);
                     }
                 }
-                __syncthreads();
+                HC_U(2);
+                HC_SYNC_ROUND();
+                HC_U(3);
+            }
+            if (si + m_len < sn) {
+                // the search behind the match: its bytes from the window, which then moves on
+                // (not waited for: the match after this one is its first reader)
+                const int nsi = si + m_len, wo = nsi - wb;
+                if (wo >= 0 && wo < kWave) {
+                    w_nx = rl64(W, wo);
+                    w_nx_pos = nsi;
+                    if (wo >= 24) win_fetch(nsi);
+                } else {
+                    win_fetch(nsi);
+                }
             }
 
             HC_T(5);
             HC_N(13, 1);
+            HC_M(13, 1);
             const int l_len = si - anchor;
             si += m_len;
             m_len -= kMinMatch;
 
             // ---- emit, block.go:411-449; an index panic is "failed" ----
+            if (l_len < 0xF && m_len < 0xF && di + l_len + 3 <= dlen) {
+                // the common sequence -- token, up to 14 literals, offset -- and room for all of
+                // it: the three bytes around the literals go out in one store (lanes 0..2)
+                const int at = lane == 0 ? di : di + l_len + lane;
+                const uint32_t val = lane == 0 ? (uint32_t)(m_len | (l_len << 4)) : (uint32_t)offset >> (8 * (lane - 1) & 31);
+                if (lane < 3) d[at] = (uint8_t)val;
+                di++;
+                if (lane < l_len) lit = s[anchor + lane];
+                lit_n = l_len;
+                lit_di = di;
+                di += l_len + 2;
+                anchor = si;
+                HC_T(6);
+                HC_U(4);
+                continue;
+            }
             if (di >= dlen) {
                 failed = true;
                 break;
@@ -710,6 +803,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 }
             }
             HC_T(6);
+            HC_U(4);
         }
 
         put_literals();
