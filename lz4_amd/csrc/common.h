@@ -14,12 +14,13 @@ constexpr int kWinMask = kWinSize - 1;
 constexpr int kMfLimit = 14;  // block.go:25
 constexpr int kAdaptSkipLog = 7;
 // HC chain table: links per entry (hc.hip) and the bytes of one workspace slot
-// (hashTable u32[65536] + chainTable kHcLinks x u16 [65536]).
+// (hashTable u32[65536] + chainTable kHcLinks x u16 [65536] + one byte per window position that
+// says whether the position is in the tables, hc.hip).
 #ifndef LZ4HIP_HC_LINKS
 #define LZ4HIP_HC_LINKS 64
 #endif
 constexpr int kHcLinks = LZ4HIP_HC_LINKS;
-constexpr size_t kHcSlotBytes = 65536 * 4 + (size_t)65536 * kHcLinks * 2;
+constexpr size_t kHcSlotBytes = 65536 * 4 + (size_t)65536 * kHcLinks * 2 + 65536;
 constexpr int kDstExplicit = 2;  // internal dst_mode: dst_len given explicitly (single-block API)
 
 __host__ __device__ inline uint32_t compress_bound32(uint32_t n) { return n + n / 255 + 16; }

@@ -32,6 +32,9 @@ static_assert(kHcLinks == kWave, "one link per lane");
 #ifndef LZ4HIP_HC_FRONT
 #define LZ4HIP_HC_FRONT 1  // misses in a row from which the lock-step miss front runs (0: never)
 #endif
+#ifndef LZ4HIP_HC_SCAN
+#define LZ4HIP_HC_SCAN 2048  // a batch of 64 chain members within this many positions: the walk turns into a scan (0: never)
+#endif
 #ifndef LZ4HIP_HC_FRONT_PEN
 #define LZ4HIP_HC_FRONT_PEN 63  // most searches the front sits out after confirming nothing
 #endif
@@ -50,7 +53,21 @@ static_assert(kHcLinks == kWave, "one link per lane");
 #else
 #define HC_SYNC_ROUND() __syncthreads()
 #endif
-constexpr int kHcSlotWords = (1 << 16) + (1 << 16) * kHcLinks / 2;
+constexpr int kHcSlotWords = (int)(kHcSlotBytes / 4);
+
+// The position map behind the chain table: byte p & 0xffff holds hc_gen(p) if the parse JUMPED
+// position p (a miss's step of two or more, :386-389), so that p is in no chain.  Every other
+// position that the parse has passed is in the tables, so the map says for every position of
+// the window whether it is a chain member -- what the scan of a dense chain needs to know
+// (hc_scan).  Written only inside long runs of misses; the marks repeat every 8 MiB, beyond
+// that the scan is only used where nothing was jumped.
+__device__ __forceinline__ uint8_t *hc_map(uint16_t *chain_table) {
+    return reinterpret_cast<uint8_t *>(chain_table + (size_t)kWinSize * kHcLinks);
+}
+__device__ __forceinline__ uint32_t hc_gen(int p) { return (((uint32_t)p >> 16) & 0x7Fu) + 1u; }
+__device__ __forceinline__ void hc_mark_jumped(uint8_t *map, int first, int count, int lane) {
+    for (int k = lane; k < count; k += kWave) map[(first + k) & kWinMask] = (uint8_t)hc_gen(first + k);
+}
 
 // Links of a position inserted behind `head` (distance d0 > 0, inside the window), given
 // lane j-1's link of head's entry in `inh_prev` (lane 0: unused): link 0 = d0, link j = d0 +
@@ -82,9 +99,10 @@ __device__ __forceinline__ void hc_insert(uint32_t *hash_table, uint16_t *chain_
 // first stride; the few long ones decide how long the wave waits, so after the first stride
 // the compare runs 32 bytes per round trip (four strides in flight) while 32 more bytes are
 // inside lim -- the same first differing byte is found either way.
-__device__ __forceinline__ int hc_prefix_len(const uint8_t *s, int next, int si, int lim, uint64_t w_si) {
-    int ml = 0;
-    {
+__device__ __forceinline__ int hc_prefix_len(const uint8_t *s, int next, int si, int lim, uint64_t w_si,
+                                             bool stride1_equal = false) {
+    int ml = 8;
+    if (!stride1_equal) {
         const uint64_t x = ld64(s + next) ^ w_si;  // w_si: the 8 bytes at si (every lane would load the same)
         if (x != 0) return __builtin_ctzll(x) >> 3;
         ml = 8;
@@ -265,6 +283,134 @@ __device__ __forceinline__ void hc_insert_run(uint32_t *hash_table, uint16_t *ch
     }
 }
 
+// The rest of a dense chain's walk as a scan of the source (see k_hc_compress): the members of h's
+// chain below `top` are the window's positions whose 4 bytes hash to h (and, where positions
+// were jumped, that the position map shows), in descending order.  Returns the winner as
+// m_len | offset << 32.
+__device__ __forceinline__ uint64_t hc_scan(const uint8_t *__restrict__ s, const uint8_t *__restrict__ map, int n,
+                                                      int si, int next, uint32_t h, uint64_t w, int lim, int ml_max,
+                                                      int m_len, int offset, bool jumped, int lane) {
+    uint64_t gate_w = 0;
+    if (m_len >= LZ4HIP_HC_GATE) gate_w = ld64(s + si + m_len - 7);
+        const int lo = si - (kWinSize - 1) > 1 ? si - (kWinSize - 1) : 1;
+        int top = next;
+        // the first chunk's bytes; inside the loop the next chunk's are asked for
+        // before this chunk is looked at
+        uint64_t a0 = 0, a1 = 0;
+        {
+            const int pb = (top & ~511) + lane * 8;
+            if (pb <= top) {
+                a0 = ld64(s + pb);
+                a1 = ld64(s + pb + 8);
+            }
+        }
+        while (top >= lo && m_len < ml_max) {
+            const int cb = top & ~511, pb = cb + lane * 8;
+            // the gate's bytes of the lane's 8 positions (index m_len - 7 .. m_len + 7 from
+            // pb) in one stretch as well, where the block has them
+            const bool gated = m_len >= LZ4HIP_HC_GATE;
+            const bool stretch = gated && top + m_len + 10 <= n;
+            uint64_t b0 = 0, b1 = 0;
+            if (stretch && pb <= top) {
+                b0 = ld64(s + pb + m_len - 7);
+                b1 = ld64(s + pb + m_len + 1);
+            }
+            uint64_t mk = 0;  // the map's bytes of the lane's 8 positions
+            if (jumped && pb <= top) mk = *reinterpret_cast<const uint64_t *>(map + (pb & kWinMask));
+            uint64_t na0 = 0, na1 = 0;
+            {
+                const int npb = cb - 512 + lane * 8;
+                if (cb - 1 >= lo) {
+                    na0 = ld64(s + npb);
+                    na1 = ld64(s + npb + 8);
+                }
+            }
+            // Per lane, one bit per position pb + j (the work of this loop is what a dense
+            // chain costs now -- all resident waves scan at once -- so it is kept to 32-bit
+            // operations: the 4 bytes at offset k of a 16-byte stretch are one v_alignbyte).
+            const int jlo = lo - pb > 0 ? lo - pb : 0, jhi = top - pb < 7 ? top - pb : 7;
+            uint32_t memb = jhi >= jlo ? ((2u << jhi) - 1u) & ~((1u << jlo) - 1u) : 0u;  // inside [lo, top]
+            if (jumped) {  // ... and not jumped by the parse
+                const uint32_t g = hc_gen(pb), mlo = (uint32_t)mk, mhi = (uint32_t)(mk >> 32);
+                uint32_t out = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    out |= (((j < 4 ? mlo : mhi) >> (8 * (j & 3))) & 0xFFu) == g ? 1u << j : 0u;
+                memb &= ~out;
+            }
+            const uint32_t wlo = (uint32_t)w, whi = (uint32_t)(w >> 32);
+            uint32_t V[12];
+            {
+                const uint32_t A[4] = {(uint32_t)a0, (uint32_t)(a0 >> 32), (uint32_t)a1, (uint32_t)(a1 >> 32)};
+#pragma unroll
+                for (int k = 0; k < 12; k++)
+                    V[k] = (k & 3) == 0 ? A[k >> 2] : __builtin_amdgcn_alignbyte(A[(k >> 2) + 1], A[k >> 2], k & 3);
+            }
+            uint32_t hm = 0, eql = 0, eqh = 0;  // hash is h; bytes 0..3 / 4..7 are si's
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                hm |= hash4(V[j]) == h ? 1u << j : 0u;
+                eql |= V[j] == wlo ? 1u << j : 0u;
+                eqh |= V[j + 4] == whi ? 1u << j : 0u;
+            }
+            memb &= hm;
+            // members equal to si over 8 bytes: the gate, then the full compare
+            uint32_t need = memb & eql & eqh;
+            if (stretch) {
+                const uint32_t B[4] = {(uint32_t)b0, (uint32_t)(b0 >> 32), (uint32_t)b1, (uint32_t)(b1 >> 32)};
+                const uint32_t glo = (uint32_t)gate_w, ghi = (uint32_t)(gate_w >> 32);
+                uint32_t gm = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int k = j + 4;
+                    const uint32_t g0 = (j & 3) == 0 ? B[j >> 2] : __builtin_amdgcn_alignbyte(B[(j >> 2) + 1], B[j >> 2], j & 3);
+                    const uint32_t g1 = (k & 3) == 0 ? B[k >> 2] : __builtin_amdgcn_alignbyte(B[(k >> 2) + 1], B[k >> 2], k & 3);
+                    gm |= (g0 == glo && g1 == ghi) ? 1u << j : 0u;
+                }
+                need &= gm;
+            }
+            int bml = 0, bj = 0;  // the lane's best so far
+            if (m_len < 8) {
+                // members that differ from si inside the first 8 bytes, but behind byte m_len
+                const uint32_t himask = m_len >= 7 ? ~0u : m_len >= 4 ? (1u << (8 * (m_len - 3))) - 1u : 0u;
+                const uint32_t part = memb & eql & ~eqh;
+#pragma unroll
+                for (int j = 7; j >= 0; j--) {
+                    const uint32_t xh = V[j + 4] ^ whi;
+                    if ((part >> j & 1u) && (xh & himask) == 0) {
+                        const int ml1 = 4 + (int)(__builtin_ctz(xh) >> 3);
+                        if (ml1 > bml) bml = ml1, bj = j;  // descending j: a tie keeps the nearer
+                    }
+                }
+                if (bml <= m_len) bml = 0;
+            }
+            // the candidates equal to si over 8 bytes (and at the gate): the full compare
+            while (ballot(need != 0)) {
+                if (need) {
+                    const int j = 31 - __builtin_clz(need);
+                    need &= ~(1u << j);
+                    const int q = pb + j;
+                    const bool gate = !gated || stretch || ld64(s + q + m_len - 7) == gate_w;
+                    if (gate) {
+                        const int ml2 = hc_prefix_len(s, q, si, lim, w, true);
+                        if (ml2 > m_len && ml2 > bml) bml = ml2, bj = j;
+                    }
+                }
+            }
+            if (ballot(bml != 0)) {
+                const int key = bml ? (bml << 9) | (lane * 8 + bj) : 0;
+                const int best = wave_max(key);
+                m_len = best >> 9;
+                offset = si - (cb + (best & 511));
+                if (m_len >= LZ4HIP_HC_GATE) gate_w = ld64(s + si + m_len - 7);
+            }
+            top = cb - 1;
+            a0 = na0;
+            a1 = na1;
+        }
+    return (uint64_t)(uint32_t)m_len | ((uint64_t)(uint32_t)offset << 32);
+}
+
 // -DLZ4HIP_HC_PROF (profiling builds only, tools/prof): shader-clock cycles summed over all waves,
 // [0..3] searches by batches walked (none, one, 2-8, more), [4] waiting-position bookkeeping and
 // the per-search store, [5] insertion rounds, [6] emission, [7] set-up and tail; counts: [8..11]
@@ -346,6 +492,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             // ever reached from a head or a link written in this block, after the entry itself
             uint4 *t4 = reinterpret_cast<uint4 *>(hash_table);
             for (int k = lane; k < (1 << 16) / 4; k += kWave) t4[k] = make_uint4(0, 0, 0, 0);
+            uint4 *m4 = reinterpret_cast<uint4 *>(hc_map(chain_table));  // no position was jumped
+#pragma unroll 1
+            for (int k = lane; k < kWinSize / 16; k += kWave) m4[k] = make_uint4(0, 0, 0, 0);
         }
         __syncthreads();
 
@@ -391,6 +540,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l) |
                    ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32);
         };
+        // The last position that may NOT be in the tables although the parse has passed it: one that
+        // a miss's step of two or more jumped (:386-389), or one inserted under a mixed value behind
+        // a match longer than the window (:399-400).  64 KiB behind it, the chain of a hash is
+        // exactly the window's positions with that hash (see the scan below).
+        int last_skip = -kWinSize;
+        int last_mixed = -kWinSize;  // ... of the second kind: there the map cannot help
         int miss_run = 0;          // searches that missed since the last match
         int fr_pen = 0, fr_skip = 0;  // the miss front backs off where it confirms nothing (text)
         // A sequence's literals (up to 64) are read at emission and stored at the end of the next
@@ -487,6 +642,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                     }
                     *(uint4_a *)(chain_table + (size_t)(P & kWinMask) * kHcLinks + 8 * t) = o;
                     if (t == 0) hash_table[hq] = (uint32_t)P;
+                    // the positions that the step behind this search jumps
+                    for (int k = t; k < ((P - anchor) >> kAdaptSkipLog); k += 8)
+                        hc_map(chain_table)[(P + 1 + k) & kWinMask] = (uint8_t)hc_gen(P + 1 + k);
                 }
                 HC_N(15, m);
                 HC_T(7);
@@ -500,11 +658,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 } else {
                     fr_pen >>= 1;
                 }
-                if (m == 8) {
-                    si = q;
-                    continue;
-                }
-                si = __builtin_amdgcn_readlane(P, 8 * m);
+                const int si_new = m == 8 ? q : __builtin_amdgcn_readlane(P, (8 * m) & 63);
+                // steps only grow inside a run of misses: the last one says whether any jumped
+                if (m > 0 && si_new - __builtin_amdgcn_readlane(P, (8 * (m - 1)) & 63) > 1) last_skip = si_new - 1;
+                si = si_new;
+                if (m == 8) continue;
                 if (si >= sn) break;
             }
             if (fr_skip > 0) fr_skip--;
@@ -620,6 +778,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                         // si's side of the gate: it changes with the held length only
                         if (m_len >= LZ4HIP_HC_GATE) gate_w = ld64(s + si + m_len - 7);
                     }
+#if LZ4HIP_HC_SCAN > 0
+                    // ---- A dense chain (runs of zero words: every earlier one a candidate, 26 k of
+                    // them on average where kernel-image data has them) costs one dependent fetch per
+                    // 64 members however it is walked.  Where every position of the window is known
+                    // to be in the tables, the members of h's chain are simply the window's
+                    // positions whose 4 bytes hash to h, in descending order -- so the rest of the
+                    // walk is done as a SCAN of the source below `next`: 512 positions per step,
+                    // 8 consecutive ones per lane from one 16-byte load, no dependent fetch at all.
+                    // Same candidates in the same order (`tries` cannot run out: it exceeds the
+                    // window), same winner: longest, ties to the nearest.
+                    const bool jumped = si - last_skip < kWinSize;  // then the position map says which
+                    if (cur - next <= LZ4HIP_HC_SCAN && in_window(next) && tries >= (uint32_t)kWinSize &&
+                        si - last_mixed >= kWinSize && (!jumped || si < (1 << 23)) && m_len < ml_max) {
+                        const uint8_t *map = hc_map(chain_table);
+                        const uint64_t r = hc_scan(s, map, n, si, next, h, w, lim, ml_max, m_len, offset, jumped, lane);
+                        m_len = (int)(uint32_t)r;
+                        offset = (int)(uint32_t)(r >> 32);
+                        next = 0;  // the walk is over
+                    }
+#endif
                 }
             }
 #ifdef LZ4HIP_HC_PROF
@@ -641,6 +819,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             HC_M(12, 1);
 
             if (m_len == 0) {  // :386-389
+                if (si - anchor >= (1 << kAdaptSkipLog)) {
+                    last_skip = si + ((si - anchor) >> kAdaptSkipLog);
+                    hc_mark_jumped(hc_map(chain_table), si + 1, (si - anchor) >> kAdaptSkipLog, lane);
+                }
                 si += 1 + ((si - anchor) >> kAdaptSkipLog);
                 miss_run++;
                 continue;
@@ -713,6 +895,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                     // (:399-400).  When the window clamp skips positions (match
                     // longer than 64 KiB) the first three values mix old and new
                     // bytes; reproduce that, it decides which slots are written.
+                    last_mixed = end - 1;
                     for (; p < end; p++) {
                         match = (match >> 8) | ((uint32_t)s[p + 3] << 24);
                         hc_insert(hash_table, chain_table, hash4(match), p, lane);

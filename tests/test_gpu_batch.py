@@ -308,6 +308,54 @@ def test_hc_waiting_positions_are_inserted_in_time(T, oracle, depth):
     _check_blocks(T, oracle, np.concatenate(blocks), bs, depth)
 
 
+def _dense_chain_block(rng, n):
+    """Kernel-image-like bytes for the HC kernel's miss front and dense-chain scan (hc.hip): runs of
+    one value of every length (their 4-byte words are chains of thousands), records with zero
+    fields, and incompressible stretches of every length with a few of those words INSIDE them --
+    positions that the parse jumps (steps of 2 .. 200, block.go:386-389) and that are therefore in
+    no chain, although their bytes hash like the chain's."""
+    out = []
+    size = 0
+    fill = int(rng.integers(0, 3)) * 0x55  # 0x00, 0x55, 0xAA
+    while size < n:
+        k = int(rng.integers(0, 7))
+        if k == 0:
+            a = np.full(int(rng.integers(4, 700)), fill, np.uint8)
+        elif k == 1:
+            a = rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8)
+        elif k == 2:  # long noise with the chain's word sprinkled in: jumped members
+            a = rng.integers(0, 256, int(rng.choice([300, 2000, 9000, 30000])), dtype=np.uint8)
+            for q in rng.integers(0, a.size - 8, a.size // int(rng.choice([40, 150, 600])) + 1):
+                a[q:q + int(rng.integers(4, 9))] = fill
+        elif k == 3:  # records: a counter and zero fields
+            m = int(rng.integers(4, 200))
+            rec = np.full((m, 16), fill, np.uint8)
+            rec[:, 0] = np.arange(m) & 0xFF
+            rec[:, 5] = rng.integers(0, 4, m)
+            a = rec.reshape(-1)
+        elif k == 4:
+            a = np.full(int(rng.integers(4, 100)), 0xFF, np.uint8)
+        elif k == 5:  # the same word at a short period: collisions of position, not of value
+            a = np.tile(np.array([fill] * 4 + [1, 2, 3], np.uint8), int(rng.integers(2, 80)))
+        else:
+            a = np.full(int(rng.integers(2000, 9000)), fill, np.uint8)
+            a[rng.integers(0, a.size, a.size // 97)] = rng.integers(1, 256, a.size // 97, dtype=np.uint8)
+        out.append(a)
+        size += a.size
+    return np.concatenate(out)[:n]
+
+
+@pytest.mark.parametrize("depth,bs,seed", [(131072, 1 << 18, 1), (131072, 1 << 20, 2), (0, 1 << 18, 3),
+                                           (65535, 1 << 18, 4), (131072, 1 << 16, 5), (40, 1 << 18, 6)])
+def test_hc_miss_front_and_dense_chain_scan(T, oracle, depth, bs, seed):
+    """hc.hip takes runs of misses eight searches at a time and turns the walk of a dense chain
+    into a scan of the window (only where `depth` cannot run out, and with the position map where
+    the parse jumped positions): same bytes as the reference's one candidate at a time."""
+    rng = np.random.default_rng(seed)
+    nb = 6 if bs <= (1 << 18) else 2
+    _check_blocks(T, oracle, np.concatenate([_dense_chain_block(rng, bs) for _ in range(nb)]), bs, depth)
+
+
 def test_sharded_frame_path_world1_device_ops(T, oracle):
     """lz4_amd.shard with the real device ops (world size 1, RCCL backend), both
     directions: span assembly, the hosted and the device content-checksum chain, the

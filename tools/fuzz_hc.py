@@ -1,8 +1,8 @@
 """One-off wide fuzz of the batched HC compressor against the oracle:
     python tools/fuzz_hc.py [SEED]
 Adversarial synthetic blocks (runs, short periods, tiny alphabets, noisy text, sorted bytes, long
-runs of a few values, a repeated far segment) -- the long chains, the gate behind a held match and
-the run insertion -- at 64 KiB / 256 KiB / 1 MiB blocks and depths 1 .. 131072, frame dst mode
+runs of a few values, a repeated far segment, dense chains with jumped members) -- the long chains,
+the gate behind a held match, the run insertion, the miss front and the dense-chain scan -- at 64 KiB / 256 KiB / 1 MiB blocks and depths 1 .. 131072, frame dst mode
 (dst = len(src): overflow and "not compressible" outcomes included)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,7 +16,26 @@ binary = corpus.generate("binary", 0, 1 << 22)
 
 
 def piece(n, deep):
-    k = int(rng.integers(0, 9))
+    k = int(rng.integers(0, 11))
+    if k >= 9:  # dense chains with members that the parse jumps (the scan and its position map, hc.hip)
+        out, size, fill = [], 0, int(rng.integers(0, 3)) * 0x55
+        while size < n:
+            j = int(rng.integers(0, 4))
+            if j == 0:
+                a = np.full(int(rng.integers(4, 700)), fill, np.uint8)
+            elif j == 1:
+                a = rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8)
+            elif j == 2:
+                a = rng.integers(0, 256, int(rng.choice([300, 2000, 9000, 30000])), dtype=np.uint8)
+                for q in rng.integers(0, a.size - 8, a.size // int(rng.choice([40, 150, 600])) + 1):
+                    a[q:q + int(rng.integers(4, 9))] = fill
+            else:
+                m = int(rng.integers(4, 200))
+                rec = np.full((m, 16), fill, np.uint8)
+                rec[:, 0] = np.arange(m) & 0xFF
+                a = rec.reshape(-1)
+            out.append(a); size += a.size
+        return np.concatenate(out)[:n]
     if k == 2 and deep:   # a tiny alphabet makes 64 Ki-candidate chains at every position:
         k = 3             # hours on the CPU side at full depth
     if k == 0:
