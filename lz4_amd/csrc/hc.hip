@@ -33,7 +33,7 @@ static_assert(kHcLinks == kWave, "one link per lane");
 #define LZ4HIP_HC_FRONT 1  // misses in a row from which the lock-step miss front runs (0: never)
 #endif
 #ifndef LZ4HIP_HC_SCAN
-#define LZ4HIP_HC_SCAN 2048  // a batch of 64 chain members within this many positions: the walk turns into a scan (0: never)
+#define LZ4HIP_HC_SCAN 256  // a batch of 64 chain members within this many positions: the walk turns into a scan (0: never)
 #endif
 #ifndef LZ4HIP_HC_FRONT_PEN
 #define LZ4HIP_HC_FRONT_PEN 63  // most searches the front sits out after confirming nothing
@@ -284,11 +284,12 @@ __device__ __forceinline__ void hc_insert_run(uint32_t *hash_table, uint16_t *ch
 }
 
 // The rest of a dense chain's walk as a scan of the source (see k_hc_compress): the members of h's
-// chain below `top` are the window's positions whose 4 bytes hash to h (and, where positions
-// were jumped, that the position map shows), in descending order.  Returns the winner as
+// chain below `top` are the window's positions whose 4 bytes hash to h (except, where positions
+// were jumped, those that the position map shows), in descending order; of them only those
+// with si's own 4 bytes can be matches, so only those are looked at.  Returns the winner as
 // m_len | offset << 32.
 __device__ __forceinline__ uint64_t hc_scan(const uint8_t *__restrict__ s, const uint8_t *__restrict__ map, int n,
-                                                      int si, int next, uint32_t h, uint64_t w, int lim, int ml_max,
+                                                      int si, int next, uint64_t w, int lim, int ml_max,
                                                       int m_len, int offset, bool jumped, int lane) {
     uint64_t gate_w = 0;
     if (m_len >= LZ4HIP_HC_GATE) gate_w = ld64(s + si + m_len - 7);
@@ -346,38 +347,33 @@ __device__ __forceinline__ uint64_t hc_scan(const uint8_t *__restrict__ s, const
                 for (int k = 0; k < 12; k++)
                     V[k] = (k & 3) == 0 ? A[k >> 2] : __builtin_amdgcn_alignbyte(A[(k >> 2) + 1], A[k >> 2], k & 3);
             }
-            uint32_t hm = 0, eql = 0, eqh = 0;  // hash is h; bytes 0..3 / 4..7 are si's
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                hm |= hash4(V[j]) == h ? 1u << j : 0u;
-                eql |= V[j] == wlo ? 1u << j : 0u;
-                eqh |= V[j + 4] == whi ? 1u << j : 0u;
-            }
-            memb &= hm;
-            // members equal to si over 8 bytes: the gate, then the full compare
-            uint32_t need = memb & eql & eqh;
+            // Only a member whose first 4 bytes are si's can be a match (:361-373), and such a position
+            // has si's hash: the hash of the others need not be looked at -- they change nothing.
+            // bit j of need: position pb + j is equal to si over 8 bytes and at the gate
+            uint32_t need = 0;
             if (stretch) {
                 const uint32_t B[4] = {(uint32_t)b0, (uint32_t)(b0 >> 32), (uint32_t)b1, (uint32_t)(b1 >> 32)};
                 const uint32_t glo = (uint32_t)gate_w, ghi = (uint32_t)(gate_w >> 32);
-                uint32_t gm = 0;
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const int k = j + 4;
                     const uint32_t g0 = (j & 3) == 0 ? B[j >> 2] : __builtin_amdgcn_alignbyte(B[(j >> 2) + 1], B[j >> 2], j & 3);
                     const uint32_t g1 = (k & 3) == 0 ? B[k >> 2] : __builtin_amdgcn_alignbyte(B[(k >> 2) + 1], B[k >> 2], k & 3);
-                    gm |= (g0 == glo && g1 == ghi) ? 1u << j : 0u;
+                    need |= (V[j] == wlo && V[k] == whi && g0 == glo && g1 == ghi) ? 1u << j : 0u;
                 }
-                need &= gm;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) need |= (V[j] == wlo && V[j + 4] == whi) ? 1u << j : 0u;
             }
+            need &= memb;
             int bml = 0, bj = 0;  // the lane's best so far
             if (m_len < 8) {
                 // members that differ from si inside the first 8 bytes, but behind byte m_len
                 const uint32_t himask = m_len >= 7 ? ~0u : m_len >= 4 ? (1u << (8 * (m_len - 3))) - 1u : 0u;
-                const uint32_t part = memb & eql & ~eqh;
 #pragma unroll
                 for (int j = 7; j >= 0; j--) {
                     const uint32_t xh = V[j + 4] ^ whi;
-                    if ((part >> j & 1u) && (xh & himask) == 0) {
+                    if ((memb >> j & 1u) && V[j] == wlo && xh != 0 && (xh & himask) == 0) {
                         const int ml1 = 4 + (int)(__builtin_ctz(xh) >> 3);
                         if (ml1 > bml) bml = ml1, bj = j;  // descending j: a tie keeps the nearer
                     }
@@ -792,7 +788,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                     if (cur - next <= LZ4HIP_HC_SCAN && in_window(next) && tries >= (uint32_t)kWinSize &&
                         si - last_mixed >= kWinSize && (!jumped || si < (1 << 23)) && m_len < ml_max) {
                         const uint8_t *map = hc_map(chain_table);
-                        const uint64_t r = hc_scan(s, map, n, si, next, h, w, lim, ml_max, m_len, offset, jumped, lane);
+                        const uint64_t r = hc_scan(s, map, n, si, next, w, lim, ml_max, m_len, offset, jumped, lane);
                         m_len = (int)(uint32_t)r;
                         offset = (int)(uint32_t)(r >> 32);
                         next = 0;  // the walk is over
