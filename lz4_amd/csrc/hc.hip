@@ -394,10 +394,11 @@ __device__ __forceinline__ uint64_t hc_scan(const uint8_t *__restrict__ s, const
                 }
             }
             if (ballot(bml != 0)) {
-                const int key = bml ? (bml << 9) | (lane * 8 + bj) : 0;
-                const int best = wave_max(key);
-                m_len = best >> 9;
-                offset = si - (cb + (best & 511));
+                // the longest; among equals the nearest = the highest position (lengths reach 2^30 in
+                // a single-block call: no room for the position in one 32-bit key)
+                m_len = wave_max(bml);
+                const int sel = 63 - __builtin_clzll(ballot(bml == m_len));
+                offset = si - (cb + sel * 8 + __builtin_amdgcn_readlane(bj, sel));
                 if (m_len >= LZ4HIP_HC_GATE) gate_w = ld64(s + si + m_len - 7);
             }
             top = cb - 1;
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
         // the search behind it -- is then in registers when that match is found (text: a match
         // every 10 bytes; each of these was a round trip the wave sat out).
         uint64_t W = 0;
-        int wb = -(1 << 30);
+        int wb = -(1 << 20);  // (nothing fetched yet)
         auto win_fetch = [&](int base) {
             wb = base;
             W = 0;
@@ -767,10 +768,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                     // longer candidate replaces the held one (:373-379), and on a long walk most
                     // batches have none: one ballot says so and the reduction is skipped
                     if (ballot(ml >= kMinMatch && ml > m_len)) {
-                        const int key = ml >= kMinMatch ? (ml << 6) | (63 - lane) : 0;
-                        const int best = wave_max(key);
-                        m_len = best >> 6;
-                        offset = si - __builtin_amdgcn_readlane(mine, 63 - (best & 63));
+                        // (two steps: lengths reach 2^30 in a single-block call, which leaves no
+                        // room for the lane in one 32-bit key)
+                        m_len = wave_max(ml);
+                        offset = si - __builtin_amdgcn_readlane(mine, __builtin_ctzll(ballot(ml == m_len)));
                         // si's side of the gate: it changes with the held length only
                         if (m_len >= LZ4HIP_HC_GATE) gate_w = ld64(s + si + m_len - 7);
                     }

@@ -186,3 +186,24 @@ def test_quirk_paths_differential(oracle):
             for hc in (None, 1, 4, 65536):
                 assert _gpu_compress(lz, src, dst_len, hc) == _cpu_compress(oracle, src, dst_len, hc), \
                     (n, dst_len, hc, src[:16])
+
+
+def test_hc_single_block_beyond_32mib_match(oracle):
+    """One call, 40 MiB: a run longer than 2^25 bytes (the match length alone fills most of a 32-bit
+    word: the winner is picked in two steps, hc.hip), noise that the parse steps over in growing
+    jumps, and dense zero words behind the 8 MiB mark, where the position map's marks repeat and the
+    dense-chain scan must not trust them (block.go:319-481)."""
+    import lz4_amd as lz
+    rng = np.random.default_rng(11)
+    parts = [rng.integers(0, 256, 3000, dtype=np.uint8), np.zeros((34 << 20) + 123, np.uint8)]
+    noise = rng.integers(0, 256, 2 << 20, dtype=np.uint8)
+    for q in rng.integers(0, noise.size - 8, 20000):
+        noise[q:q + 4] = 0
+    parts.append(noise)
+    tail = np.zeros(3 << 20, np.uint8)
+    tail[rng.integers(0, tail.size, tail.size // 61)] = rng.integers(1, 256, tail.size // 61, dtype=np.uint8)
+    parts.append(tail)
+    parts.append(noise[:1 << 20])
+    src = np.concatenate(parts).tobytes()
+    bound = lz.CompressBlockBound(len(src))
+    assert _gpu_compress(lz, src, bound, 131072) == _cpu_compress(oracle, src, bound, 131072)
