@@ -17,7 +17,7 @@ constexpr int kAdaptSkipLog = 7;
 // (hashTable u32[65536] + chainTable kHcLinks x u16 [65536] + one byte per window position that
 // says whether the position is in the tables, hc.hip).
 #ifndef LZ4HIP_HC_LINKS
-#define LZ4HIP_HC_LINKS 64
+#define LZ4HIP_HC_LINKS 32
 #endif
 constexpr int kHcLinks = LZ4HIP_HC_LINKS;
 constexpr size_t kHcSlotBytes = 65536 * 4 + (size_t)65536 * kHcLinks * 2 + 65536;

@@ -18,14 +18,17 @@ namespace lz4hip {
 
 // Per-slot workspace: hashTable u32[65536], then the chain table, kHcLinks u16 per entry.
 // The reference's chainTable[p & 0xffff] holds the previous position with p's hash
-// (block.go:382-383).  Here the entry holds the distances from p to the 1st .. 64th
+// (block.go:382-383).  Here the entry holds the distances from p to the 1st .. kL-th
 // previous positions of its chain, as u16 (0 = none, or 65536 or more away: the
-// reference's walk stops there anyway, `si-next < winSize`, :355) -- one 128-byte line, one
-// link per lane.  Links of older positions never change, so links 2.. are link 1 plus the
-// links of the previous head's entry at insertion time.  A walk then costs ONE dependent
-// fetch per 64 candidates instead of one per candidate, in the same candidate order, and
-// the fetch of the next entry is in flight while the current 64 candidates are compared.
-static_assert(kHcLinks == kWave, "one link per lane");
+// reference's walk stops there anyway, `si-next < winSize`, :355) -- one 64-byte line for
+// kL = 32 (the default: half the entry traffic of 64 links, and the chains that were the
+// reason for 64 are scanned now, hc_scan), one link per lane of the lower half-wave.  Links of
+// older positions never change, so links 2.. are link 1 plus the links of the previous
+// head's entry at insertion time.  A walk then costs ONE dependent fetch per kL candidates
+// instead of one per candidate, in the same candidate order, and the fetch of the next entry
+// is in flight while the current batch is compared.
+static_assert(kHcLinks == kWave || kHcLinks == kWave / 2, "one link per lane, of all lanes or of the lower half");
+constexpr int kL = kHcLinks;
 #ifndef LZ4HIP_HC_GATE
 #define LZ4HIP_HC_GATE 8  // held match length from which the one-load gate precedes the prefix compare
 #endif
@@ -86,10 +89,10 @@ __device__ __forceinline__ void hc_insert(uint32_t *hash_table, uint16_t *chain_
     uint32_t l = 0;
     if (head > 0 && p - head < kWinSize) {
         uint32_t hl = 0;
-        if (lane > 0) hl = chain_table[(size_t)(head & kWinMask) * kHcLinks + lane - 1];
+        if (lane > 0 && lane < kL) hl = chain_table[(size_t)(head & kWinMask) * kHcLinks + lane - 1];
         l = hc_link((uint32_t)(p - head), hl, lane);
     }
-    chain_table[(size_t)(p & kWinMask) * kHcLinks + lane] = (uint16_t)l;
+    if (lane < kL) chain_table[(size_t)(p & kWinMask) * kHcLinks + lane] = (uint16_t)l;
     __syncthreads();  // every lane has read the old head
     if (lane == 0) hash_table[hh] = (uint32_t)p;
 }
@@ -234,7 +237,7 @@ __device__ __forceinline__ void hc_insert_round(uint32_t *hash_table, uint16_t *
         for (int q = 0; q < kHcLinks / 8; q++) r[q] = make_uint4(e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]);
     }
     if (ride && pre.head > 0 && pre.pos - pre.head < kWinSize)
-        pre.l = chain_table[(size_t)(pre.head & kWinMask) * kHcLinks + lane];
+        pre.l = lane < kL ? chain_table[(size_t)(pre.head & kWinMask) * kHcLinks + lane] : 0;
     __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // ---- twins, in position order: from the twin's finished row (LDS operations of one wave
     // execute in order, so a row written by one step is what the next step reads) ----
@@ -249,17 +252,17 @@ __device__ __forceinline__ void hc_insert_round(uint32_t *hash_table, uint16_t *
         uint32_t l = 0;
         if (d != 0) {
             uint32_t inh = 0;
-            if (lane > 0) inh = rows[t * kRowStride + lane - 1];
+            if (lane > 0 && lane < kL) inh = rows[t * kRowStride + lane - 1];
             l = hc_link(d, inh, lane);
         }
-        rows[i * kRowStride + lane] = (uint16_t)l;
+        if (lane < kL) rows[i * kRowStride + lane] = (uint16_t)l;
         __asm__ volatile("" ::: "memory");
     }
     __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // ---- the finished rows go out, 16 bytes per lane ----
 #pragma unroll
     for (int it = 0; it < kHcLinks / 8; it++) {
-        const int c = lane + it * kWave, row = c >> 3, col = c & 7;
+        const int c = lane + it * kWave, row = c / (kL / 8), col = c % (kL / 8);
         const int prow = __shfl(p, row);  // all lanes shuffle; only the rows that exist are stored
         if (row < cnt) {
             const uint4 v = *(const uint4_a *)(rows + row * kRowStride + col * 8);
@@ -603,11 +606,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 int head = 0;
                 if (!bad) head = (int)hash_table[hq];
                 const bool inw = !bad && head > 0 && P - head < kWinSize;
-                uint4 e = make_uint4(0, 0, 0, 0);  // links 8t .. 8t+7 of the head's entry
+                uint4 e = make_uint4(0, 0, 0, 0);  // the lane's kL/8 links of the head's entry, from link t*kL/8 on
                 uint32_t c0 = 0, c1 = 0;           // links t-1 and t+7: candidates t and t+8
                 if (inw) {
                     const uint16_t *ent = chain_table + (size_t)(head & kWinMask) * kHcLinks;
-                    e = *(const uint4_a *)(ent + 8 * t);
+                    if (kL == kWave) {
+                        e = *(const uint4_a *)(ent + 8 * t);
+                    } else {
+                        const uint2 e2 = *(const uint2 __attribute__((may_alias)) *)(ent + 4 * t);
+                        e.x = e2.x, e.y = e2.y;
+                    }
                     if (t > 0) c0 = ent[t - 1];
                     c1 = ent[t + 7];
                 }
@@ -620,11 +628,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 if (v0) x0 = ld32(s + cand0) ^ (uint32_t)w;
                 if (v1) x1 = ld32(s + cand1) ^ (uint32_t)w;
                 // a 17th candidate (link 15) inside the window: not for the front
-                if (inw && t == 1 && depth > 16u) {
-                    const uint32_t l15 = e.w >> 16;
+                if (inw && t == (kL == kWave ? 1 : 3) && depth > 16u) {
+                    const uint32_t l15 = (kL == kWave ? e.w : e.y) >> 16;
                     if (l15 != 0 && P - (head - (int)l15) < kWinSize) bad = true;
                 }
-                const uint32_t prev7 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(e.w >> 16), 0x111, 0xF, 0xF, false);
+                const uint32_t prev7 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)((kL == kWave ? e.w : e.y) >> 16), 0x111, 0xF, 0xF, false);
                 if (x0 == 0 || x1 == 0) bad = true;  // four equal bytes: a match
                 const uint64_t B = ballot(bad);
                 const int m = B ? (int)(__builtin_ctzll(B) >> 3) : 8;
@@ -634,10 +642,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                         const uint32_t d0 = (uint32_t)(P - head);
                         o.x = (t == 0 ? d0 : hc_shift(prev7, d0)) | (hc_shift(e.x & 0xFFFFu, d0) << 16);
                         o.y = hc_shift(e.x >> 16, d0) | (hc_shift(e.y & 0xFFFFu, d0) << 16);
-                        o.z = hc_shift(e.y >> 16, d0) | (hc_shift(e.z & 0xFFFFu, d0) << 16);
-                        o.w = hc_shift(e.z >> 16, d0) | (hc_shift(e.w & 0xFFFFu, d0) << 16);
+                        if (kL == kWave) {
+                            o.z = hc_shift(e.y >> 16, d0) | (hc_shift(e.z & 0xFFFFu, d0) << 16);
+                            o.w = hc_shift(e.z >> 16, d0) | (hc_shift(e.w & 0xFFFFu, d0) << 16);
+                        }
                     }
-                    *(uint4_a *)(chain_table + (size_t)(P & kWinMask) * kHcLinks + 8 * t) = o;
+                    if (kL == kWave)
+                        *(uint4_a *)(chain_table + (size_t)(P & kWinMask) * kHcLinks + 8 * t) = o;
+                    else
+                        *(uint2 __attribute__((may_alias)) *)(chain_table + (size_t)(P & kWinMask) * kHcLinks + 4 * t) = make_uint2(o.x, o.y);
                     if (t == 0) hash_table[hq] = (uint32_t)P;
                     // the positions that the step behind this search jumps
                     for (int k = t; k < ((P - anchor) >> kAdaptSkipLog); k += 8)
@@ -716,7 +729,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 auto in_window = [&](int q) { return q > 0 && si - q < kWinSize; };
                 // `l`: lane j's link of cur's entry, fetched one batch ahead
                 uint32_t l = 0;
-                if (in_window(next)) l = ridden ? pre.l : chain_table[(size_t)(next & kWinMask) * kHcLinks + lane];
+                if (in_window(next) && lane < kL) l = ridden ? pre.l : chain_table[(size_t)(next & kWinMask) * kHcLinks + lane];
                 bool first = true;
                 uint64_t gate_w = 0;
                 while (tries > 0 && in_window(next) && m_len < ml_max) {
@@ -731,7 +744,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                     // lane k: link k-1 (DPP wave_shr:1; lane 0 gets 0 and does not use it)
                     const uint32_t lk = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)l, 0x138, 0xF, 0xF, false);
                     const int mine = lane == 0 ? cur : cur - (int)lk;
-                    const bool valid = lane == 0 || (lk != 0 && si - mine < kWinSize);
+                    const bool valid = lane == 0 || (lane < kL && lk != 0 && si - mine < kWinSize);
                     if (first) {
                         // chainTable[si] = hashTable[h] (:382): si's entry is the distances to
                         // exactly these candidates -- no second look at the table needed
@@ -744,15 +757,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                     if ((uint32_t)cnt > tries) cnt = (int)tries;
                     tries -= (uint32_t)cnt;
                     next = 0;
-                    if (nv == kWave && tries > 0) {
-                        const uint32_t l63 = (uint32_t)__builtin_amdgcn_readlane((int)l, kWave - 1);
+                    if (nv == kL && tries > 0) {
+                        const uint32_t l63 = (uint32_t)__builtin_amdgcn_readlane((int)l, kL - 1);
                         if (l63 != 0) next = cur - (int)l63;  // window check: loop condition
                     }
                     // the next entry's fetch flies while this batch is compared
                     // (straight into l, whose old value is used up: through a second variable the
                     // compiler copies it at once and waits for the fetch right here)
                     l = 0;
-                    if (in_window(next)) l = chain_table[(size_t)(next & kWinMask) * kHcLinks + lane];
+                    if (in_window(next) && lane < kL) l = chain_table[(size_t)(next & kWinMask) * kHcLinks + lane];
                     int ml = 0;
                     if (lane < cnt) {
                         // The reference's gate (:358-360) as a shortcut once a long match is
@@ -786,7 +799,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                     // Same candidates in the same order (`tries` cannot run out: it exceeds the
                     // window), same winner: longest, ties to the nearest.
                     const bool jumped = si - last_skip < kWinSize;  // then the position map says which
-                    if (cur - next <= LZ4HIP_HC_SCAN && in_window(next) && tries >= (uint32_t)kWinSize &&
+                    if (cur - next <= LZ4HIP_HC_SCAN * kL / kWave && in_window(next) && tries >= (uint32_t)kWinSize &&
                         si - last_mixed >= kWinSize && (!jumped || si < (1 << 23)) && m_len < ml_max) {
                         const uint8_t *map = hc_map(chain_table);
                         const uint64_t r = hc_scan(s, map, n, si, next, w, lim, ml_max, m_len, offset, jumped, lane);
@@ -808,7 +821,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             // hc_insert(si): the entry was derived above (all zero when there was no head
             // inside the window); the head moves to si
             put_literals();  // behind the search's own loads
-            chain_table[(size_t)(si & kWinMask) * kHcLinks + lane] = (uint16_t)my_link;
+            if (lane < kL) chain_table[(size_t)(si & kWinMask) * kHcLinks + lane] = (uint16_t)my_link;
             if (lane == 0) hash_table[h] = (uint32_t)si;
             HC_U(0);
             HC_SYNC_SEARCH();

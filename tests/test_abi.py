@@ -71,7 +71,7 @@ def test_argument_validation_without_gpu():
     assert lib.lz4hip_compress_fast_blocks(16, 100, 1 << 16, 0, 16, 1024, 16, None, 0, None) == _lib.ERR_ARG
     assert lib.lz4hip_uncompress_blocks(None, 0, None, None, 4, None, 0, 0, None, 0, None, None) == _lib.ERR_ARG
     # heads + 64 u16 links per entry (one 128-byte line), + 256 bytes for the block counter of the schedule
-    assert lib.lz4hip_hc_workspace_bytes(1) == 65536 * 4 + 65536 * 64 * 2 + 65536 + 256  # heads, links, position map, counter
+    assert lib.lz4hip_hc_workspace_bytes(1) == 65536 * 4 + 65536 * 32 * 2 + 65536 + 256  # heads, 32 links per position, position map, counter
 
 
 def test_xxh32_host_update_chain_without_gpu(oracle):
