@@ -41,21 +41,6 @@ constexpr int kL = kHcLinks;
 #ifndef LZ4HIP_HC_FRONT_PEN
 #define LZ4HIP_HC_FRONT_PEN 63  // most searches the front sits out after confirming nothing
 #endif
-// experiment switch: which store acknowledgements the wave waits for (1: none after a search's
-// stores, 2: none after an insertion round)
-#ifndef LZ4HIP_HC_NOSYNC
-#define LZ4HIP_HC_NOSYNC 0
-#endif
-#if LZ4HIP_HC_NOSYNC & 1
-#define HC_SYNC_SEARCH() __asm__ volatile("" ::: "memory")
-#else
-#define HC_SYNC_SEARCH() __syncthreads()
-#endif
-#if LZ4HIP_HC_NOSYNC & 2
-#define HC_SYNC_ROUND() __asm__ volatile("" ::: "memory")
-#else
-#define HC_SYNC_ROUND() __syncthreads()
-#endif
 constexpr int kHcSlotWords = (int)(kHcSlotBytes / 4);
 
 // The position map behind the chain table: byte p & 0xffff holds hc_gen(p) if the parse JUMPED
@@ -270,7 +255,7 @@ __device__ __forceinline__ void hc_insert_round(uint32_t *hash_table, uint16_t *
         }
     }
     if (act && !later) hash_table[hh] = (uint32_t)p;
-    HC_SYNC_ROUND();  // the next round gathers what this one stored, and reuses the rows
+    __syncthreads();  // the next round gathers what this one stored, and reuses the rows
 }
 
 __device__ __forceinline__ void hc_insert_run(uint32_t *hash_table, uint16_t *chain_table,
@@ -824,7 +809,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             if (lane < kL) chain_table[(size_t)(si & kWinMask) * kHcLinks + lane] = (uint16_t)my_link;
             if (lane == 0) hash_table[h] = (uint32_t)si;
             HC_U(0);
-            HC_SYNC_SEARCH();
+            __syncthreads();
             HC_U(8);
             HC_M(12, 1);
 
@@ -912,7 +897,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                     }
                 }
                 HC_U(2);
-                HC_SYNC_ROUND();
+                __syncthreads();
                 HC_U(3);
             }
             if (si + m_len < sn) {
