@@ -360,6 +360,8 @@ __device__ __forceinline__ void team_walker(const uint8_t *__restrict__ s, const
     uint32_t spins = 0;
     TP_DECL;
     uint32_t e_done_seen = 0;   // the encoder's count as last read: re-read only when the ring looks full
+    int pf_w = -1;              // the window whose records were read ahead
+    uint32_t pf_seq = 0, pf_r0 = 0, pf_r1 = 0, pf_r2 = 0, pf_x = 0;
     auto e_slot_wait = [&]() {  // room for record k
         while (k >= e_done_seen + kRingE) {
             e_done_seen = lds_ld(&S->e_done);
@@ -384,7 +386,10 @@ __device__ __forceinline__ void team_walker(const uint8_t *__restrict__ s, const
         // word that says "window w" are window w's); they are read again only if the producer
         // was not there yet.
         uint32_t r0, r1, r2, xlo;
-        for (;;) {
+        // (asked for while the window before was walked, if its producer was done by then)
+        const bool ahead = pf_w == w && rfl(pf_seq) == (uint32_t)w + 1;
+        r0 = pf_r0, r1 = pf_r1, r2 = pf_r2, xlo = pf_x;
+        for (; !ahead;) {
             const uint32_t seq = __hip_atomic_load(&S->a_seq[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __asm__ volatile("" ::: "memory");
             r0 = S->a_rec[sl][0][lane], r1 = S->a_rec[sl][1][lane], r2 = S->a_rec[sl][2][lane];
@@ -457,6 +462,18 @@ __device__ __forceinline__ void team_walker(const uint8_t *__restrict__ s, const
         uint64_t P = pending ? 1ull << (si - 2 - wbase) : 0ull;  // put(si-2) of the match that ended the last window
         pending = false;
 
+        // The next window's sequence word and records, asked for now: the reads complete under
+        // the walk, and if the sequence word already says "window w + 1" they are that window's
+        // (a slot is rewritten only several windows on), so the next turn starts without the wait.
+        {
+            const int sn1 = a_slot(w + 1);
+            pf_w = w + 1;
+            pf_seq = __hip_atomic_load(&S->a_seq[sn1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __asm__ volatile("" ::: "memory");
+            pf_r0 = S->a_rec[sn1][0][lane], pf_r1 = S->a_rec[sn1][1][lane], pf_r2 = S->a_rec[sn1][2][lane];
+            pf_x = ring32(ring, wbase + kTeamStride + lane);
+            __asm__ volatile("" ::: "memory");
+        }
         TP_T(1);
         // ================= Phase B: fast_common.h for the common steps, the rest here =========
         for (;;) {
