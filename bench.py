@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--frame-gib", type=float, default=16.0,
                     help="GiB per GPU for the cfg5 frame path after the timed region (cfg5's share is 16 "
                          "GiB = 4096 blocks of 4 MiB; halved while free HBM does not allow it; 0: skip)")
+    ap.add_argument("--hc-gib", type=float, default=4.0,
+                    help="GiB per corpus of the cfg4 (HC Level9) extra section on rank 0 (0: skip)")
     ap.add_argument("--cpu-sample-mib", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -358,6 +360,38 @@ def main():
             frame_path = fp
         except Exception as e:  # the headline line must survive a failure of this extra section
             frame_path = {"error": "%s: %s" % (type(e).__name__, e)}
+    # ---- cfg4 (HC Level9, 4 GiB of 1 MiB blocks per corpus) on rank 0: an extra key, not the headline ----
+    if rank == 0 and args.hc_gib > 0 and isinstance(frame_path, dict):
+        try:
+            torch.cuda.empty_cache()
+            n_hc = int(args.hc_gib * (1 << 30))
+            hc = {"workload": "cfg4: %.2f GiB per corpus, 1MB blocks, HC depth 131072 (Level9), one wave per block"
+                              % (n_hc / 2**30)}
+            for kind in ("binary", "text"):
+                src_h = corpus.generate_device(kind, n_hc, device)
+                nb_h = n_hc >> 20
+                from lz4_amd import _lib as _l
+                ws_h = torch.empty(_l.load().lz4hip_hc_workspace_bytes(nb_h), dtype=torch.uint8, device=device)
+                out_h = torch.empty((nb_h, 1 << 20), dtype=torch.uint8, device=device)
+                res_h = torch.zeros(nb_h, dtype=torch.int32, device=device)
+                dev.compress_blocks(src_h[:1 << 24], 1 << 20, 131072, out=out_h, result=res_h, workspace=ws_h)  # warm-up
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                outs = dev.compress_blocks(src_h, 1 << 20, 131072, out=out_h, result=res_h, workspace=ws_h)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1)
+                res = outs[1]
+                csz = int(torch.where(res > 0, res, torch.full_like(res, 1 << 20)).sum().item())
+                hc[kind + "_GBps"] = round(n_hc / ms / 1e6, 3)
+                hc[kind + "_ms"] = round(ms, 1)
+                hc[kind + "_ratio"] = round(csz / n_hc, 4)
+                del src_h, outs, res, ws_h, out_h, res_h
+                torch.cuda.empty_cache()
+            frame_path["hc_cfg4"] = hc
+        except Exception as e:
+            frame_path["hc_cfg4"] = {"error": "%s: %s" % (type(e).__name__, e)}
     emit(frame_path)
 
     dist.barrier()
