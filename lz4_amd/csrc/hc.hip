@@ -400,6 +400,8 @@ __device__ __forceinline__ uint64_t hc_scan(const uint8_t *__restrict__ s, const
 // [0..3] searches by batches walked (none, one, 2-8, more), [4] waiting-position bookkeeping and
 // the per-search store, [5] insertion rounds, [6] emission, [7] set-up and tail; counts: [8..11]
 // searches of those four kinds, [12] batches, [13] matches, [14] insertion rounds.
+// (Since the round-3 kernel sits at the 128-register cap the 16 counters go to scratch and a
+// marked build runs 3-4x slower: read the counts, not the shares.)
 #ifdef LZ4HIP_HC_PROF2  // experiment marks (LZ4HIP_PROF_RAW=1 prints the slots): see HC_U below
 #define LZ4HIP_HC_PROF
 #endif
