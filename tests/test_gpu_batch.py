@@ -346,13 +346,14 @@ def _dense_chain_block(rng, n):
 
 
 @pytest.mark.parametrize("depth,bs,seed", [(131072, 1 << 18, 1), (131072, 1 << 20, 2), (0, 1 << 18, 3),
-                                           (65535, 1 << 18, 4), (131072, 1 << 16, 5), (40, 1 << 18, 6)])
+                                           (65535, 1 << 18, 4), (131072, 1 << 16, 5), (40, 1 << 18, 6),
+                                           (131072, 1 << 22, 7)])
 def test_hc_miss_front_and_dense_chain_scan(T, oracle, depth, bs, seed):
     """hc.hip takes runs of misses eight searches at a time and turns the walk of a dense chain
     into a scan of the window (only where `depth` cannot run out, and with the position map where
     the parse jumped positions): same bytes as the reference's one candidate at a time."""
     rng = np.random.default_rng(seed)
-    nb = 6 if bs <= (1 << 18) else 2
+    nb = 6 if bs <= (1 << 18) else 2 if bs <= (1 << 20) else 1
     _check_blocks(T, oracle, np.concatenate([_dense_chain_block(rng, bs) for _ in range(nb)]), bs, depth)
 
 
