@@ -189,11 +189,29 @@ __device__ __forceinline__ void hc_insert_round(uint32_t *hash_table, uint16_t *
     if (pre.pos >= 0 && ballot(act && hh == pre.h)) pre.ok = false;
     int twin = -1;        // nearest earlier lane with my hash
     bool later = false;   // a later lane has my hash: it, not I, ends up in the table
-    for (int i = 0; i < cnt; i++) {
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)hh, i);
-        if (act && hh == hi) {
-            if (lane > i) twin = i;
-            if (lane < i) later = true;
+    {
+        // Lanes that share their hash with another lane are few (none in most rounds of text): they
+        // are found through a small table in the rows' LDS (still free here) -- every lane writes
+        // its number into the slot of its hash, a lane that reads back another number flags the
+        // slot, and the lanes of flagged slots (same hash, or only the same slot) are then
+        // compared one by one, in lane order, instead of all 64.
+        uint16_t *slot = rows + (hh & 1023u);
+        if (act) *slot = (uint16_t)lane;
+        __asm__ volatile("" ::: "memory");
+        const uint32_t seen = act ? *slot : (uint32_t)lane;
+        __asm__ volatile("" ::: "memory");
+        if (act && seen != (uint32_t)lane) *slot = 0x8000u;
+        __asm__ volatile("" ::: "memory");
+        uint64_t G = ballot(act && (*slot & 0x8000u));
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        while (G) {
+            const int i = __builtin_ctzll(G);
+            G &= G - 1;
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)hh, i);
+            if (act && hh == hi) {
+                if (lane > i) twin = i;
+                if (lane < i) later = true;
+            }
         }
     }
     const int twin_pos = __shfl(p, twin < 0 ? lane : twin);  // every lane takes part in the shuffle
