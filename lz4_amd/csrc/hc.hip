@@ -57,6 +57,20 @@ __device__ __forceinline__ void hc_mark_jumped(uint8_t *map, int first, int coun
     for (int k = lane; k < count; k += kWave) map[(first + k) & kWinMask] = (uint8_t)hc_gen(first + k);
 }
 
+// hc_shift on both halves of a word at once (packed 16-bit operations): each half x becomes
+// x + d0 if x != 0 and the sum stays below 65536, else 0.
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t hc_shift2(uint32_t m, uint32_t d0) {
+    const us2_t x = __builtin_bit_cast(us2_t, m);
+    const us2_t dd = {(unsigned short)d0, (unsigned short)d0};
+    const us2_t one = {1, 1};
+    const us2_t sum = x + dd;                                         // wraps at 65536
+    const us2_t wrapped = sum ^ __builtin_elementwise_max(sum, x);    // 0 where it did not wrap
+    const us2_t keep = __builtin_elementwise_min(wrapped, one) - one;  // 0xFFFF where it did not
+    const us2_t nz = (us2_t){0, 0} - __builtin_elementwise_min(x, one);  // 0xFFFF where x != 0
+    return __builtin_bit_cast(uint32_t, (us2_t)(sum & keep & nz));
+}
+
 // Links of a position inserted behind `head` (distance d0 > 0, inside the window), given
 // lane j-1's link of head's entry in `inh_prev` (lane 0: unused): link 0 = d0, link j = d0 +
 // head's link j-1 while that stays inside the window.
@@ -232,8 +246,8 @@ __device__ __forceinline__ void hc_insert_round(uint32_t *hash_table, uint16_t *
             // word k of the new entry = links 2k, 2k+1 = the head's links 2k-1, 2k moved by d0
 #pragma unroll
             for (int k = kHcLinks / 2 - 1; k > 0; k--)
-                e[k] = hc_shift(e[k - 1] >> 16, d0) | (hc_shift(e[k] & 0xFFFFu, d0) << 16);
-            e[0] = d0 | (hc_shift(e[0] & 0xFFFFu, d0) << 16);
+                e[k] = hc_shift2(__builtin_amdgcn_alignbit(e[k], e[k - 1], 16), d0);
+            e[0] = d0 | hc_shift2(e[0] << 16, d0);
         }
         uint4_a *r = (uint4_a *)(rows + lane * kRowStride);
 #pragma unroll
